@@ -1,0 +1,10 @@
+"""h264-fer_amd -- host-side mirror of the fer_h264 encoder interface over libferhip.
+
+The product is the C-ABI shared library ``libferhip.so`` (HIP kernels for gfx950, see
+``include/ferhip.h``).  This package only binds it with ctypes so that tests and the
+benchmark can drive it the way the reference's GUI drives ``fer_h264::Starter``
+(F/fer_h264.cpp:166-216): set parameters, feed pictures, collect the byte stream.
+There is no CPU fallback: if the library or a GPU is missing, calls raise.
+"""
+from .ferhip import FerHip, FerHipError, lib_path, load_library  # noqa: F401
+from .synth import gen_frame, gen_frames, crop_to_mb  # noqa: F401

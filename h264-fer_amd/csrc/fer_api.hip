@@ -1,0 +1,645 @@
+// fer_api.hip -- the C ABI of libferhip (include/ferhip.h): context, HBM layout, picture
+// driver (the RBSP_encode sequence of F/rbsp_encoding.cpp:139-323 expressed as kernel
+// launches), host-side slice / parameter-set headers (F/headers_and_parameter_sets.cpp) and
+// NAL framing (F/nal.cpp:261-299).  Host code is C-style C++; nothing here runs the hot path
+// on the CPU.
+#include "../../include/ferhip.h"
+#include "fer_internal.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#define CK(x)                                                                                         \
+    do {                                                                                              \
+        hipError_t e_ = (x);                                                                          \
+        if (e_ != hipSuccess) {                                                                       \
+            fprintf(stderr, "ferhip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return FERHIP_E_HIP;                                                                      \
+        }                                                                                             \
+    } while (0)
+
+struct StreamState {  // slice-level state of one stream (globals `shd`, statics of RBSP_encode)
+    int frame_num, poc_lsb, idr_pic_id, first_idr_done, frames_done, have_dpb;
+};
+
+struct ferhip_ctx {
+    FerDev d;
+    ferhip_params p;
+    hipStream_t st;
+    std::vector<StreamState> ss;
+    std::vector<void *> allocs;
+    FerSortTmp sort;
+    uint32_t *h_hdr;       // pinned [S][4]
+    uint32_t *h_len;       // pinned [S]
+    int *h_status;         // pinned [S]
+    unsigned long long *h_sad;
+    std::vector<int> types;
+    uint8_t *planes[2];    // two picture sets, swapped after every picture
+    int cur_set;
+    bool refprep_valid;
+};
+
+static const int k_qpc[52] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
+                              18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33,
+                              34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
+
+template <typename T>
+static int dalloc(ferhip_ctx *c, T **p, size_t n)
+{
+    void *v = nullptr;
+    if (hipMalloc(&v, n * sizeof(T) + 256) != hipSuccess) return FERHIP_E_HIP;
+    if (hipMemset(v, 0, n * sizeof(T) + 256) != hipSuccess) return FERHIP_E_HIP;
+    c->allocs.push_back(v);
+    *p = (T *)v;
+    return 0;
+}
+
+static void bind_planes(ferhip_ctx *c)
+{
+    FerDev &d = c->d;
+    size_t fsz = d.ysz + 2 * d.csz;
+    uint8_t *cur = c->planes[c->cur_set], *ref = c->planes[c->cur_set ^ 1];
+    d.curY = cur;
+    d.curCb = cur + (size_t)d.S * d.ysz;
+    d.curCr = cur + (size_t)d.S * (d.ysz + d.csz);
+    d.refY = ref;
+    d.refCb = ref + (size_t)d.S * d.ysz;
+    d.refCr = ref + (size_t)d.S * (d.ysz + d.csz);
+    (void)fsz;
+}
+
+extern "C" const char *ferhip_version(void) { return "ferhip 0.1 (gfx950)"; }
+
+extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params *p)
+{
+    if (!out || !p || W <= 0 || H <= 0 || (W & 15) || (H & 15) || S <= 0 || W > 16384 || H > 16384) return FERHIP_E_ARG;
+    if (p->qp < 0 || p->qp > 51 || p->window < 16 || p->intra_every <= 0) return FERHIP_E_ARG;
+    if (p->basic) return FERHIP_E_UNSUP;  // BasicInterEncoding's extra exhaustive pass is not implemented
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        fprintf(stderr, "ferhip: no HIP device; the hot path has no CPU fallback\n");
+        return FERHIP_E_HIP;
+    }
+    ferhip_ctx *c = new ferhip_ctx();
+    memset(&c->d, 0, sizeof c->d);
+    c->p = *p;
+    FerDev &d = c->d;
+    d.W = W;
+    d.H = H;
+    d.Wc = W / 2;
+    d.Hc = H / 2;
+    d.mbw = W / 16;
+    d.mbh = H / 16;
+    d.nmb = d.mbw * d.mbh;
+    d.S = S;
+    d.qp = p->qp;
+    d.qpc = k_qpc[p->qp];  // chroma_qp_index_offset == 0 (F/headers_and_parameter_sets.cpp:490)
+    d.window = p->window;
+    d.maxdiff_set = p->maxdiff;
+    d.basic = 0;
+    d.ysz = (size_t)W * H;
+    d.csz = d.ysz / 4;
+    CK(hipStreamCreate(&c->st));
+    size_t fsz = d.ysz * 3 / 2;
+    int rc = 0;
+    rc |= dalloc(c, &c->planes[0], fsz * S);
+    rc |= dalloc(c, &c->planes[1], fsz * S);
+    rc |= dalloc(c, &d.interp, d.ysz * 16 * S);
+    rc |= dalloc(c, &d.feat, d.ysz * 80 * S);
+    rc |= dalloc(c, &d.sort_pos, d.ysz * S);
+    rc |= dalloc(c, &d.sort_k12, d.ysz * S);
+    rc |= dalloc(c, &d.koliko, (size_t)16385 * S);
+    size_t nm = (size_t)d.nmb * S;
+    rc |= dalloc(c, &d.mb_type, nm);
+    rc |= dalloc(c, &d.mv, nm * 8);
+    rc |= dalloc(c, &d.mvd, nm * 8);
+    rc |= dalloc(c, &d.cbp, nm * 2);
+    rc |= dalloc(c, &d.tc, nm * 24);
+    rc |= dalloc(c, &d.i4mode, nm * 16);
+    rc |= dalloc(c, &d.i4flag, nm * 16);
+    rc |= dalloc(c, &d.chroma_mode, nm);
+    rc |= dalloc(c, &d.levels, nm * FER_LEVELS);
+    rc |= dalloc(c, &d.suma, nm * 20);
+    rc |= dalloc(c, &d.st3, nm * 4 * 33 * 3);
+    rc |= dalloc(c, &d.st3n, nm * 4);
+    rc |= dalloc(c, &d.st2, nm * 4 * FER_ST2_CAP * 2);
+    rc |= dalloc(c, &d.st2n, nm * 4);
+    rc |= dalloc(c, &d.mb_bits, ((size_t)d.nmb + 1) * S);
+    d.bits_cap_words = ((size_t)d.nmb * 1024 + 4096) / 4;
+    rc |= dalloc(c, &d.bits, d.bits_cap_words * S);
+    rc |= dalloc(c, &d.hdr, (size_t)4 * S);
+    rc |= dalloc(c, &d.out_bytes, (size_t)S);
+    rc |= dalloc(c, &d.status, (size_t)S);
+    rc |= dalloc(c, &d.sad, (size_t)S);
+    rc |= dalloc(c, &d.stats, (size_t)5 * S);
+    int n = W * H;
+    c->sort.tmp_bytes = fer_sort_tmp_bytes(n);
+    rc |= dalloc(c, &c->sort.keys_in, (size_t)n);
+    rc |= dalloc(c, &c->sort.keys_out, (size_t)n);
+    rc |= dalloc(c, &c->sort.vals_in, (size_t)n);
+    rc |= dalloc(c, &c->sort.vals_out, (size_t)n);
+    uint8_t *tmp = nullptr;
+    rc |= dalloc(c, &tmp, c->sort.tmp_bytes);
+    c->sort.tmp = tmp;
+    if (rc) {
+        ferhip_destroy(c);
+        return FERHIP_E_HIP;
+    }
+    CK(hipHostMalloc((void **)&c->h_hdr, sizeof(uint32_t) * 4 * S));
+    CK(hipHostMalloc((void **)&c->h_len, sizeof(uint32_t) * S));
+    CK(hipHostMalloc((void **)&c->h_status, sizeof(int) * S));
+    CK(hipHostMalloc((void **)&c->h_sad, sizeof(unsigned long long) * S));
+    c->ss.assign(S, StreamState{0, 0, 0, 0, 0, 0});
+    c->types.assign(S, 2);
+    c->cur_set = 0;
+    c->refprep_valid = false;
+    bind_planes(c);
+    *out = c;
+    return 0;
+}
+
+extern "C" void ferhip_destroy(ferhip_ctx *c)
+{
+    if (!c) return;
+    hipStreamSynchronize(c->st);
+    for (void *p : c->allocs) hipFree(p);
+    if (c->h_hdr) hipHostFree(c->h_hdr);
+    if (c->h_len) hipHostFree(c->h_len);
+    if (c->h_status) hipHostFree(c->h_status);
+    if (c->h_sad) hipHostFree(c->h_sad);
+    hipStreamDestroy(c->st);
+    delete c;
+}
+
+// [S][Y|U|V] interleaved per stream  <->  plane-major [Y of all streams][U ...][V ...]
+static int copy_frames(ferhip_ctx *c, uint8_t *set, const uint8_t *src, uint8_t *dst, hipMemcpyKind kind)
+{
+    FerDev &d = c->d;
+    size_t fsz = d.ysz * 3 / 2;
+    for (int s = 0; s < d.S; s++) {
+        uint8_t *py = set + (size_t)s * d.ysz;
+        uint8_t *pu = set + (size_t)d.S * d.ysz + (size_t)s * d.csz;
+        uint8_t *pv = set + (size_t)d.S * (d.ysz + d.csz) + (size_t)s * d.csz;
+        if (src) {
+            const uint8_t *f = src + (size_t)s * fsz;
+            CK(hipMemcpyAsync(py, f, d.ysz, kind, c->st));
+            CK(hipMemcpyAsync(pu, f + d.ysz, d.csz, kind, c->st));
+            CK(hipMemcpyAsync(pv, f + d.ysz + d.csz, d.csz, kind, c->st));
+        } else {
+            uint8_t *f = dst + (size_t)s * fsz;
+            CK(hipMemcpyAsync(f, py, d.ysz, kind, c->st));
+            CK(hipMemcpyAsync(f + d.ysz, pu, d.csz, kind, c->st));
+            CK(hipMemcpyAsync(f + d.ysz + d.csz, pv, d.csz, kind, c->st));
+        }
+    }
+    return 0;
+}
+
+extern "C" int ferhip_set_frames(ferhip_ctx *c, const void *src, int host)
+{
+    if (!c || !src) return FERHIP_E_ARG;
+    int rc = copy_frames(c, c->planes[c->cur_set], (const uint8_t *)src, nullptr,
+                         host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice);
+    if (rc) return rc;
+    if (host) CK(hipStreamSynchronize(c->st));
+    return 0;
+}
+
+extern "C" int ferhip_set_reference(ferhip_ctx *c, const void *src)
+{
+    if (!c || !src) return FERHIP_E_ARG;
+    int rc = copy_frames(c, c->planes[c->cur_set ^ 1], (const uint8_t *)src, nullptr, hipMemcpyHostToDevice);
+    if (rc) return rc;
+    CK(hipStreamSynchronize(c->st));
+    for (auto &s : c->ss) s.have_dpb = 1;
+    c->refprep_valid = false;
+    return 0;
+}
+
+extern "C" int ferhip_get_recon(ferhip_ctx *c, void *dst, int host)
+{
+    if (!c || !dst) return FERHIP_E_ARG;
+    // after encode_picture the reconstruction is the reference set
+    int rc = copy_frames(c, c->planes[c->cur_set ^ 1], nullptr, (uint8_t *)dst,
+                         host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+    if (rc) return rc;
+    CK(hipStreamSynchronize(c->st));
+    return 0;
+}
+
+// ---- host bit writer for headers (MSB first, F/rbsp_IO.cpp:123)
+struct HBits {
+    unsigned long long v;
+    int n;
+    void put(int k, unsigned x)
+    {
+        v = (v << k) | (unsigned long long)x;
+        n += k;
+    }
+    void ue(unsigned x)
+    {
+        int p = 0;
+        while (((x + 1) >> (p + 1)) != 0) p++;
+        put(p, 0);
+        put(1, 1);
+        if (p) put(p, x + 1 - (1u << p));
+    }
+    void se(int x) { ue(x <= 0 ? (unsigned)(-x) * 2u : (unsigned)x * 2u - 1u); }
+};
+
+struct ByteW {
+    uint8_t *b;
+    size_t cap, nbits;
+    void put(int k, unsigned x)
+    {
+        for (int i = k - 1; i >= 0; i--) {
+            size_t by = nbits >> 3;
+            if (by < cap) {
+                if ((nbits & 7) == 0) b[by] = 0;
+                b[by] |= (uint8_t)(((x >> i) & 1u) << (7 - (nbits & 7)));
+            }
+            nbits++;
+        }
+    }
+    void ue(unsigned x)
+    {
+        int p = 0;
+        while (((x + 1) >> (p + 1)) != 0) p++;
+        put(p, 0);
+        put(1, 1);
+        if (p) put(p, x + 1 - (1u << p));
+    }
+    void se(int x) { ue(x <= 0 ? (unsigned)(-x) * 2u : (unsigned)x * 2u - 1u); }
+    size_t trailing()
+    {
+        put(1, 1);
+        while (nbits & 7) put(1, 0);
+        return nbits >> 3;
+    }
+};
+
+// sps_write, F/headers_and_parameter_sets.cpp:305-391
+extern "C" size_t ferhip_write_sps(ferhip_ctx *c, uint8_t *rbsp, size_t cap)
+{
+    ByteW w{rbsp, cap, 0};
+    w.put(8, 66);
+    w.put(1, 1);
+    w.put(1, 1);
+    w.put(1, 0);
+    w.put(5, 0);
+    w.put(8, 41);
+    w.ue(0);
+    w.ue(5);  // log2_max_frame_num 9
+    w.ue(0);
+    w.ue(6);  // log2_max_pic_order_cnt_lsb 10
+    w.ue(1);
+    w.put(1, 0);
+    w.ue((unsigned)(c->d.mbw - 1));
+    w.ue((unsigned)(c->d.mbh - 1));
+    w.put(1, 1);
+    w.put(1, 1);
+    w.put(1, 0);
+    w.put(1, 0);
+    return w.trailing();
+}
+
+// pps_write, F/headers_and_parameter_sets.cpp:478-513 (weighted_bipred_idc field carries the value 1)
+extern "C" size_t ferhip_write_pps(ferhip_ctx *c, uint8_t *rbsp, size_t cap)
+{
+    ByteW w{rbsp, cap, 0};
+    w.ue(0);
+    w.ue(0);
+    w.put(1, 0);
+    w.put(1, 0);
+    w.ue(0);
+    w.ue(0);
+    w.ue(0);
+    w.put(1, 0);
+    w.put(2, 1);
+    w.se(14 + c->p.qp - 26);
+    w.se(0);
+    w.se(0);
+    w.put(1, 0);
+    w.put(1, 0);
+    w.put(1, 0);
+    return w.trailing();
+}
+
+// writeNAL, F/nal.cpp:261-299
+extern "C" size_t ferhip_write_nal(int nal_ref_idc, int nal_type, const uint8_t *rbsp, size_t n, uint8_t *out)
+{
+    size_t pos = 0;
+    out[pos++] = 0;
+    out[pos++] = 0;
+    out[pos++] = 0;
+    out[pos++] = 1;
+    out[pos++] = (uint8_t)((nal_ref_idc << 5) | (nal_type & 31));
+    int zc = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (zc >= 2 && rbsp[i] <= 3) {
+            out[pos++] = 3;
+            zc = 0;
+        }
+        out[pos++] = rbsp[i];
+        zc = rbsp[i] == 0 ? zc + 1 : 0;
+    }
+    return pos;
+}
+
+// slice header of stream s for this picture: shd_write, F/headers_and_parameter_sets.cpp:172-239
+static void build_header(ferhip_ctx *c, int s, int nal_type)
+{
+    StreamState &t = c->ss[s];
+    int slice_type;
+    if (nal_type == FERHIP_NAL_IDR) {  // F/rbsp_encoding.cpp:142-164
+        slice_type = 2;
+        if (!t.first_idr_done) {
+            t.first_idr_done = 1;
+            t.idr_pic_id = 0;
+        } else if (t.frame_num == 0) {
+            t.idr_pic_id++;
+        } else {
+            t.idr_pic_id = 0;
+        }
+        t.frame_num = 0;
+        t.poc_lsb = 0;
+    } else {
+        slice_type = 0;
+        t.frame_num++;
+        t.poc_lsb += 2;
+    }
+    HBits h{0, 0};
+    h.ue(0);
+    h.ue((unsigned)slice_type);
+    h.ue(0);
+    h.put(9, (unsigned)t.frame_num & 511u);
+    if (nal_type == FERHIP_NAL_IDR) h.ue((unsigned)t.idr_pic_id);
+    h.put(10, (unsigned)t.poc_lsb & 1023u);
+    if (slice_type == 0) {
+        h.put(1, 0);  // num_ref_idx_active_override_flag
+        h.put(1, 0);  // ref_pic_list_modification_flag_l0
+        h.put(1, 0);  // adaptive_ref_pic_marking_mode_flag
+    } else {
+        h.put(1, 0);  // no_output_of_prior_pics_flag
+        h.put(1, 0);  // long_term_reference_flag
+    }
+    h.se(-14);
+    c->h_hdr[s * 4 + 0] = (uint32_t)(h.v >> 32);
+    c->h_hdr[s * 4 + 1] = (uint32_t)h.v;
+    c->h_hdr[s * 4 + 2] = (uint32_t)h.n;
+    c->h_hdr[s * 4 + 3] = (uint32_t)slice_type;
+    c->types[s] = slice_type;
+}
+
+static int run_picture(ferhip_ctx *c, int *nal_type)
+{
+    FerDev &d = c->d;
+    const int S = d.S;
+    // ---- selectNALUnitType, F/ref_frames.cpp:185-234
+    std::vector<int> nt(S);
+    bool need_sad = false;
+    for (int s = 0; s < S; s++) {
+        int req = nal_type ? nal_type[s] : FERHIP_NAL_AUTO;
+        StreamState &t = c->ss[s];
+        if (req == FERHIP_NAL_IDR || req == FERHIP_NAL_SLICE) {
+            nt[s] = (!t.have_dpb) ? FERHIP_NAL_IDR : req;
+        } else if (!t.have_dpb || t.frames_done % c->p.intra_every == 0) {
+            nt[s] = FERHIP_NAL_IDR;
+        } else {
+            nt[s] = -1;
+            need_sad = true;
+        }
+    }
+    if (need_sad) {
+        fer_launch_frame_sad(d, c->st);
+        CK(hipMemcpyAsync(c->h_sad, d.sad, sizeof(unsigned long long) * S, hipMemcpyDeviceToHost, c->st));
+        CK(hipStreamSynchronize(c->st));
+        for (int s = 0; s < S; s++)
+            if (nt[s] == -1) nt[s] = c->h_sad[s] > ((unsigned long long)d.nmb << 12) ? FERHIP_NAL_IDR : FERHIP_NAL_SLICE;
+    }
+    bool anyP = false, anyI = false;
+    for (int s = 0; s < S; s++) {
+        build_header(c, s, nt[s]);
+        if (nal_type) nal_type[s] = nt[s];
+        anyP |= c->types[s] == 0;
+        anyI |= c->types[s] == 2;
+    }
+    CK(hipMemcpyAsync(d.hdr, c->h_hdr, sizeof(uint32_t) * 4 * S, hipMemcpyHostToDevice, c->st));
+    if (anyP) {
+        if (!c->refprep_valid) fer_launch_refprep(d, c->sort, c->types.data(), c->st);
+        fer_launch_me(d, c->st);
+        fer_launch_p_resid(d, c->st);
+    }
+    if (anyI) fer_launch_intra(d, c->st);
+    fer_launch_cavlc(d, c->st);
+    CK(hipGetLastError());
+    // the reconstruction becomes the reference picture (frameDeepCopy, F/ref_frames.cpp:17)
+    c->cur_set ^= 1;
+    bind_planes(c);
+    c->refprep_valid = false;
+    for (int s = 0; s < S; s++) {
+        c->ss[s].have_dpb = 1;
+        c->ss[s].frames_done++;
+    }
+    return 0;
+}
+
+extern "C" int ferhip_encode_picture_dev(ferhip_ctx *c, int *nal_type, const uint8_t **d_rbsp, size_t *stride,
+                                         const uint32_t **d_rbsp_len)
+{
+    if (!c) return FERHIP_E_ARG;
+    int rc = run_picture(c, nal_type);
+    if (rc) return rc;
+    if (d_rbsp) *d_rbsp = (const uint8_t *)c->d.bits;
+    if (stride) *stride = c->d.bits_cap_words * 4;
+    if (d_rbsp_len) *d_rbsp_len = c->d.out_bytes;
+    return 0;
+}
+
+extern "C" int ferhip_encode_picture(ferhip_ctx *c, int *nal_type, uint8_t *rbsp, size_t rbsp_stride, uint32_t *rbsp_len)
+{
+    if (!c || !rbsp || !rbsp_len) return FERHIP_E_ARG;
+    int rc = run_picture(c, nal_type);
+    if (rc) return rc;
+    FerDev &d = c->d;
+    CK(hipMemcpyAsync(c->h_len, d.out_bytes, sizeof(uint32_t) * d.S, hipMemcpyDeviceToHost, c->st));
+    CK(hipMemcpyAsync(c->h_status, d.status, sizeof(int) * d.S, hipMemcpyDeviceToHost, c->st));
+    CK(hipStreamSynchronize(c->st));
+    for (int s = 0; s < d.S; s++) {
+        if (c->h_status[s]) {
+            fprintf(stderr, "ferhip: stream %d device status 0x%x\n", s, c->h_status[s]);
+            return FERHIP_E_DEVICE;
+        }
+        rbsp_len[s] = c->h_len[s];
+        if (c->h_len[s] > rbsp_stride) return FERHIP_E_ARG;
+        CK(hipMemcpyAsync(rbsp + (size_t)s * rbsp_stride, (const uint8_t *)d.bits + (size_t)s * d.bits_cap_words * 4,
+                          c->h_len[s], hipMemcpyDeviceToHost, c->st));
+    }
+    CK(hipStreamSynchronize(c->st));
+    return 0;
+}
+
+extern "C" int ferhip_encode_streams(ferhip_ctx *c, const uint8_t *frames, int nframes, uint8_t *out, size_t out_stride,
+                                     size_t *out_len, uint8_t *recon)
+{
+    if (!c || !frames || !out || !out_len || nframes <= 0) return FERHIP_E_ARG;
+    FerDev &d = c->d;
+    const int S = d.S;
+    size_t fsz = d.ysz * 3 / 2;
+    size_t rstride = d.bits_cap_words * 4;
+    std::vector<uint8_t> rbsp(rstride * S);
+    std::vector<uint32_t> len(S);
+    std::vector<int> nt(S);
+    uint8_t hdr[64];
+    for (int s = 0; s < S; s++) {
+        size_t pos = 0, n;
+        n = ferhip_write_sps(c, hdr, sizeof hdr);
+        pos += ferhip_write_nal(1, 7, hdr, n, out + (size_t)s * out_stride + pos);
+        n = ferhip_write_pps(c, hdr, sizeof hdr);
+        pos += ferhip_write_nal(1, 8, hdr, n, out + (size_t)s * out_stride + pos);
+        out_len[s] = pos;
+    }
+    for (int f = 0; f < nframes; f++) {
+        int rc = ferhip_set_frames(c, frames + (size_t)f * S * fsz, 1);
+        if (rc) return rc;
+        for (int s = 0; s < S; s++) nt[s] = FERHIP_NAL_AUTO;
+        rc = ferhip_encode_picture(c, nt.data(), rbsp.data(), rstride, len.data());
+        if (rc) return rc;
+        for (int s = 0; s < S; s++) {
+            if (out_len[s] + (size_t)len[s] * 3 / 2 + 16 > out_stride) return FERHIP_E_ARG;
+            out_len[s] += ferhip_write_nal(1, nt[s], rbsp.data() + (size_t)s * rstride, len[s],
+                                           out + (size_t)s * out_stride + out_len[s]);
+        }
+        if (recon) {
+            rc = ferhip_get_recon(c, recon + (size_t)f * S * fsz, 1);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+extern "C" int ferhip_get_stats(ferhip_ctx *c, int *out)
+{
+    if (!c || !out) return FERHIP_E_ARG;
+    CK(hipMemcpy(out, c->d.stats, sizeof(int) * 5 * c->d.S, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int ferhip_status(ferhip_ctx *c, int *out)
+{
+    if (!c || !out) return FERHIP_E_ARG;
+    CK(hipMemcpy(out, c->d.status, sizeof(int) * c->d.S, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- per-stage entry points
+static void set_all_types(ferhip_ctx *c, int slice_type)
+{
+    for (int s = 0; s < c->d.S; s++) {
+        c->h_hdr[s * 4 + 0] = c->h_hdr[s * 4 + 1] = 0;
+        c->h_hdr[s * 4 + 2] = 1;
+        c->h_hdr[s * 4 + 3] = (uint32_t)slice_type;
+        c->types[s] = slice_type;
+    }
+    hipMemcpyAsync(c->d.hdr, c->h_hdr, sizeof(uint32_t) * 4 * c->d.S, hipMemcpyHostToDevice, c->st);
+}
+
+extern "C" int ferhip_fill_interpolated(ferhip_ctx *c)
+{
+    if (!c) return FERHIP_E_ARG;
+    set_all_types(c, 0);
+    fer_launch_refprep(c->d, c->sort, nullptr, c->st);
+    CK(hipStreamSynchronize(c->st));
+    CK(hipGetLastError());
+    c->refprep_valid = true;
+    return 0;
+}
+
+extern "C" int ferhip_inter_encoding(ferhip_ctx *c)
+{
+    if (!c) return FERHIP_E_ARG;
+    set_all_types(c, 0);
+    if (!c->refprep_valid) fer_launch_refprep(c->d, c->sort, nullptr, c->st);
+    c->refprep_valid = true;
+    fer_launch_me(c->d, c->st);
+    CK(hipStreamSynchronize(c->st));
+    CK(hipGetLastError());
+    return 0;
+}
+
+extern "C" size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t cap)
+{
+    if (!c || !dst) return 0;
+    FerDev &d = c->d;
+    size_t nm = (size_t)d.nmb * d.S;
+    const void *src = nullptr;
+    size_t n = 0;
+    switch (which) {
+    case FERHIP_BUF_INTERP: src = d.interp; n = d.ysz * 16 * d.S; break;
+    case FERHIP_BUF_FEAT: src = d.feat; n = d.ysz * 80 * d.S * 2; break;
+    case FERHIP_BUF_SORTPOS: src = d.sort_pos; n = d.ysz * d.S * 4; break;
+    case FERHIP_BUF_KOLIKO: src = d.koliko; n = (size_t)16385 * d.S * 4; break;
+    case FERHIP_BUF_MBTYPE: src = d.mb_type; n = nm * 4; break;
+    case FERHIP_BUF_MV: src = d.mv; n = nm * 16; break;
+    case FERHIP_BUF_MVD: src = d.mvd; n = nm * 16; break;
+    case FERHIP_BUF_LEVELS: src = d.levels; n = nm * FER_LEVELS * 2; break;
+    case FERHIP_BUF_CBP: src = d.cbp; n = nm * 2; break;
+    case FERHIP_BUF_TC: src = d.tc; n = nm * 24; break;
+    case FERHIP_BUF_I4MODE: src = d.i4mode; n = nm * 16; break;
+    case FERHIP_BUF_CUR:
+    case FERHIP_BUF_REF: {
+        n = d.ysz * 3 / 2 * d.S;
+        if (n > cap) return 0;
+        uint8_t *set = c->planes[which == FERHIP_BUF_CUR ? c->cur_set : c->cur_set ^ 1];
+        if (copy_frames(c, set, nullptr, (uint8_t *)dst, hipMemcpyDeviceToHost)) return 0;
+        if (hipStreamSynchronize(c->st) != hipSuccess) return 0;
+        return n;
+    }
+    default: return 0;
+    }
+    if (n > cap) return 0;
+    if (hipStreamSynchronize(c->st) != hipSuccess) return 0;
+    if (hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- block-level KATs: forwardResidual / inverseResidual on the device
+__global__ void k_block_kat(int qP, const int32_t *in, int32_t *out, int keep_dc, int inverse, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int a[16], t[16], b[16];
+    for (int k = 0; k < 16; k++) a[k] = in[i * 16 + k];
+    if (inverse) {
+        inv4x4(a, b, qP, keep_dc != 0);
+    } else {
+        fwd4x4(a, t);
+        quant4x4(t, b, qP, keep_dc != 0);
+    }
+    for (int k = 0; k < 16; k++) out[i * 16 + k] = b[k];
+}
+
+static int block_kat(int qP, const int32_t *in, int32_t *out, int keep_dc, int inverse, size_t n)
+{
+    if (!in || !out || qP < 0 || qP > 51) return FERHIP_E_ARG;
+    int32_t *di = nullptr, *dout = nullptr;
+    CK(hipMalloc((void **)&di, n * 64));
+    CK(hipMalloc((void **)&dout, n * 64));
+    CK(hipMemcpy(di, in, n * 64, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_block_kat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, qP, di, dout, keep_dc, inverse, n);
+    CK(hipGetLastError());
+    CK(hipMemcpy(out, dout, n * 64, hipMemcpyDeviceToHost));
+    hipFree(di);
+    hipFree(dout);
+    return 0;
+}
+
+extern "C" int ferhip_forward_residual(int qP, const int32_t *in, int32_t *out, int keep_dc, size_t n)
+{
+    return block_kat(qP, in, out, keep_dc, 0, n);
+}
+extern "C" int ferhip_inverse_residual(int qP, const int32_t *in, int32_t *out, int keep_dc, size_t n)
+{
+    return block_kat(qP, in, out, keep_dc, 1, n);
+}

@@ -1,0 +1,380 @@
+// fer_dev.h -- device-side layout and shared device helpers of libferhip (gfx950).
+//
+// One encoder context drives S independent streams ("shards": closed GOPs that the
+// reference would encode as separate runs).  Everything a picture needs lives in HBM
+// as structure-of-arrays indexed [stream][macroblock]; the reference keeps the same
+// information in process globals (F/h264_globals.cpp:174-186, F/mode_pred.cpp:16-17,
+// F/residual.cpp:10-17, F/moestimation.cpp:21-27).  F/ = fer_h264/fer_h264/ of the
+// reference tree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FER_P_L0_16x16 0
+#define FER_P_16x8 1
+#define FER_P_8x16 2
+#define FER_P_8x8ref0 4
+#define FER_P_SKIP 31
+#define FER_MV_NA ((int)0x80808080u)
+
+#define FER_ST2_CAP 384  // stage-2 candidates kept per 8x8 partition
+#define FER_LEVELS 400   // int16 per MB: luma 16x16, dc16 16, cdc 2x4, cac 2x4x15
+#define FER_LV_DC16 256
+#define FER_LV_CDC 272
+#define FER_LV_CAC 280
+
+struct FerDev {
+    int W, H, Wc, Hc, mbw, mbh, nmb, S;
+    int qp, qpc, window, maxdiff_set, basic;
+    size_t ysz, csz;
+    // pictures: cur = `frame` (source in, reconstruction out), ref = `dpb`
+    uint8_t *curY, *curCb, *curCr;
+    uint8_t *refY, *refCb, *refCr;
+    // a16: 16 quarter-pel planes, 5 box features per plane, positions sorted by 8x8 sum
+    uint8_t *interp;     // [S][16][H][W]
+    uint16_t *feat;      // [S][16][5][H][W]
+    uint32_t *sort_pos;  // [S][W*H]  (tx << 16) | ty, ordered by (sum, tx, ty)
+    uint32_t *sort_k12;  // [S][W*H]  kar1 | kar2 << 16 of that position
+    int *koliko;         // [S][16385] bucket start offsets
+    // per-MB side information (a20)
+    int *mb_type;        // [S][nmb]
+    int *prev_mb_type;   // [S][nmb] mb_type_array left by the previous picture
+    short *mv;           // [S][nmb][4][2] one MV per 8x8 quadrant
+    short *mvd;          // [S][nmb][4][2]
+    uint8_t *cbp;        // [S][nmb][2] luma, chroma
+    uint8_t *tc;         // [S][nmb][24] TotalCoeff: luma 16, Cb 4, Cr 4
+    uint8_t *i4mode;     // [S][nmb][16]
+    uint8_t *i4flag;     // [S][nmb][16] bit3 = prev_intra4x4_pred_mode_flag, bits0-2 = rem
+    uint8_t *chroma_mode;  // [S][nmb]
+    int16_t *levels;     // [S][nmb][FER_LEVELS]
+    // motion-search precompute (neighbour independent)
+    int *suma;           // [S][nmb][4][5]
+    int *st3;            // [S][nmb][4][33][3] bx, by, sad
+    int *st3n;           // [S][nmb][4]
+    int *st2;            // [S][nmb][4][CAP][2] (tmpx & 0xffff) | tmpy << 16, D
+    int *st2n;           // [S][nmb][4]
+    // entropy coding
+    uint32_t *mb_bits;   // [S][nmb+1] bit sizes, then exclusive offsets
+    uint32_t *bits;      // [S][bits_cap_words] RBSP, big-endian bit order
+    size_t bits_cap_words;
+    uint32_t *hdr;       // [S][4] slice header: bits hi, bits lo, nbits, slice_type(0=P,2=I)
+    uint32_t *out_bytes; // [S] RBSP length
+    int *status;         // [S] sticky error flags
+    unsigned long long *sad; // [S] frame SAD for the IDR decision
+    int *stats;          // [S][5] brojTipova
+};
+
+#define FER_ERR_ST2_OVERFLOW 1
+#define FER_ERR_ZERO_SUM 2
+#define FER_ERR_BITS_OVERFLOW 4
+
+// ---------------------------------------------------------------- tables
+// CAVLC tables: H.264 Tables 9-5, 9-7..9-10 as (length, code); zig-zag; block origins.
+static __constant__ uint8_t c_ct_len[3][4][17] = {
+    {{1, 6, 8, 9, 10, 11, 13, 13, 13, 14, 14, 15, 15, 16, 16, 16, 16},
+     {0, 2, 6, 8, 9, 10, 11, 13, 13, 14, 14, 15, 15, 15, 16, 16, 16},
+     {0, 0, 3, 7, 8, 9, 10, 11, 13, 13, 14, 14, 15, 15, 16, 16, 16},
+     {0, 0, 0, 5, 6, 7, 8, 9, 10, 11, 13, 14, 14, 15, 15, 16, 16}},
+    {{2, 6, 6, 7, 8, 8, 9, 11, 11, 12, 12, 12, 13, 13, 13, 14, 14},
+     {0, 2, 5, 6, 6, 7, 8, 9, 11, 11, 12, 12, 13, 13, 14, 14, 14},
+     {0, 0, 3, 6, 6, 7, 8, 9, 11, 11, 12, 12, 13, 13, 13, 14, 14},
+     {0, 0, 0, 4, 4, 5, 6, 6, 7, 9, 11, 11, 12, 13, 13, 13, 14}},
+    {{4, 6, 6, 6, 7, 7, 7, 7, 8, 8, 9, 9, 9, 10, 10, 10, 10},
+     {0, 4, 5, 5, 5, 5, 6, 6, 7, 8, 8, 9, 9, 9, 10, 10, 10},
+     {0, 0, 4, 5, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10},
+     {0, 0, 0, 4, 4, 4, 4, 4, 5, 6, 7, 8, 8, 9, 10, 10, 10}}};
+static __constant__ uint8_t c_ct_code[3][4][17] = {
+    {{1, 5, 7, 7, 7, 7, 15, 11, 8, 15, 11, 15, 11, 15, 11, 7, 4},
+     {0, 1, 4, 6, 6, 6, 6, 14, 10, 14, 10, 14, 10, 1, 14, 10, 6},
+     {0, 0, 1, 5, 5, 5, 5, 5, 13, 9, 13, 9, 13, 9, 13, 9, 5},
+     {0, 0, 0, 3, 3, 4, 4, 4, 4, 4, 12, 12, 8, 12, 8, 12, 8}},
+    {{3, 11, 7, 7, 7, 4, 7, 15, 11, 15, 11, 8, 15, 11, 7, 9, 7},
+     {0, 2, 7, 10, 6, 6, 6, 6, 14, 10, 14, 10, 14, 10, 11, 8, 6},
+     {0, 0, 3, 9, 5, 5, 5, 5, 13, 9, 13, 9, 13, 9, 6, 10, 5},
+     {0, 0, 0, 5, 4, 6, 8, 4, 4, 4, 12, 8, 12, 12, 8, 1, 4}},
+    {{15, 15, 11, 8, 15, 11, 9, 8, 15, 11, 15, 11, 8, 13, 9, 5, 1},
+     {0, 14, 15, 12, 10, 8, 14, 10, 14, 14, 10, 14, 10, 7, 12, 8, 4},
+     {0, 0, 13, 14, 11, 9, 13, 9, 13, 10, 13, 9, 13, 9, 11, 7, 3},
+     {0, 0, 0, 12, 11, 10, 9, 8, 13, 12, 12, 12, 8, 12, 10, 6, 2}}};
+static __constant__ uint8_t c_ctdc_len[4][5] = {{2, 6, 6, 6, 6}, {0, 1, 6, 7, 8}, {0, 0, 3, 7, 8}, {0, 0, 0, 6, 7}};
+static __constant__ uint8_t c_ctdc_code[4][5] = {{1, 7, 4, 3, 2}, {0, 1, 6, 3, 3}, {0, 0, 1, 2, 2}, {0, 0, 0, 5, 0}};
+static __constant__ uint8_t c_tz_len[15][16] = {
+    {1, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 9}, {3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 6, 6, 6, 6, 0},
+    {4, 3, 3, 3, 4, 4, 3, 3, 4, 5, 5, 6, 5, 6, 0, 0}, {5, 3, 4, 4, 3, 3, 3, 4, 3, 4, 5, 5, 5, 0, 0, 0},
+    {4, 4, 4, 3, 3, 3, 3, 3, 4, 5, 4, 5, 0, 0, 0, 0}, {6, 5, 3, 3, 3, 3, 3, 3, 4, 3, 6, 0, 0, 0, 0, 0},
+    {6, 5, 3, 3, 3, 2, 3, 4, 3, 6, 0, 0, 0, 0, 0, 0}, {6, 4, 5, 3, 2, 2, 3, 3, 6, 0, 0, 0, 0, 0, 0, 0},
+    {6, 6, 4, 2, 2, 3, 2, 5, 0, 0, 0, 0, 0, 0, 0, 0}, {5, 5, 3, 2, 2, 2, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {4, 4, 3, 3, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {4, 4, 2, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 3, 1, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {2, 2, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+static __constant__ uint8_t c_tz_code[15][16] = {
+    {1, 3, 2, 3, 2, 3, 2, 3, 2, 3, 2, 3, 2, 3, 2, 1}, {7, 6, 5, 4, 3, 5, 4, 3, 2, 3, 2, 3, 2, 1, 0, 0},
+    {5, 7, 6, 5, 4, 3, 4, 3, 2, 3, 2, 1, 1, 0, 0, 0}, {3, 7, 5, 4, 6, 5, 4, 3, 3, 2, 2, 1, 0, 0, 0, 0},
+    {5, 4, 3, 7, 6, 5, 4, 3, 2, 1, 1, 0, 0, 0, 0, 0}, {1, 1, 7, 6, 5, 4, 3, 2, 1, 1, 0, 0, 0, 0, 0, 0},
+    {1, 1, 5, 4, 3, 3, 2, 1, 1, 0, 0, 0, 0, 0, 0, 0}, {1, 1, 1, 3, 3, 2, 2, 1, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 0, 1, 3, 2, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0}, {1, 0, 1, 3, 2, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, 1, 2, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+static __constant__ uint8_t c_tzdc_len[3][4] = {{1, 2, 3, 3}, {1, 2, 2, 0}, {1, 1, 0, 0}};
+static __constant__ uint8_t c_tzdc_code[3][4] = {{1, 1, 1, 0}, {1, 1, 0, 0}, {1, 0, 0, 0}};
+static __constant__ uint8_t c_rb_len[6][7] = {{1, 1, 0, 0, 0, 0, 0}, {1, 2, 2, 0, 0, 0, 0}, {2, 2, 2, 2, 0, 0, 0},
+                                       {2, 2, 2, 3, 3, 0, 0}, {2, 2, 3, 3, 3, 3, 0}, {2, 3, 3, 3, 3, 3, 3}};
+static __constant__ uint8_t c_rb_code[6][7] = {{1, 0, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0, 0}, {3, 2, 1, 0, 0, 0, 0},
+                                        {3, 2, 1, 1, 0, 0, 0}, {3, 2, 3, 2, 1, 0, 0}, {3, 0, 1, 3, 2, 5, 4}};
+// raster index (y*4+x) of scan position k (F/scaleTransform.cpp:43-47)
+static __constant__ uint8_t c_zz[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
+// x,y origin of luma 4x4 block k (F/h264_globals.cpp:209-214)
+static __constant__ uint8_t c_bx[16] = {0, 4, 0, 4, 8, 12, 8, 12, 0, 4, 0, 4, 8, 12, 8, 12};
+static __constant__ uint8_t c_by[16] = {0, 0, 4, 4, 0, 0, 4, 4, 8, 8, 12, 12, 8, 8, 12, 12};
+static __constant__ uint8_t c_cbp_intra_code[48] = {3,  29, 30, 17, 31, 18, 37, 8,  32, 38, 19, 9,  20, 10, 11, 2,
+                                             16, 33, 34, 21, 35, 22, 39, 4,  36, 40, 23, 5,  24, 6,  7,  1,
+                                             41, 42, 43, 25, 44, 26, 46, 12, 45, 47, 27, 13, 28, 14, 15, 0};
+static __constant__ uint8_t c_cbp_inter_code[48] = {0,  2,  3,  7,  4,  8,  17, 13, 5,  18, 9,  14, 10, 15, 16, 11,
+                                             1,  32, 33, 36, 34, 37, 44, 40, 35, 45, 38, 41, 39, 42, 43, 19,
+                                             6,  24, 25, 20, 26, 21, 46, 28, 27, 47, 22, 29, 23, 30, 31, 12};
+// neighbour A (left) / B (up) block of luma block k (6.4.10.4), chroma likewise
+static __constant__ uint8_t c_nbA[16] = {5, 0, 7, 2, 1, 4, 3, 6, 13, 8, 15, 10, 9, 12, 11, 14};
+static __constant__ uint8_t c_nbB[16] = {10, 11, 0, 1, 14, 15, 4, 5, 2, 3, 8, 9, 6, 7, 12, 13};
+static __constant__ uint8_t c_nbcA[4] = {1, 0, 3, 2};
+static __constant__ uint8_t c_nbcB[4] = {2, 3, 0, 1};
+
+__device__ __forceinline__ int iabs(int a) { return a < 0 ? -a : a; }
+__device__ __forceinline__ int clip255(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
+__device__ __forceinline__ int iclamp(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// 16*v[m][class] (F/scaleTransform.cpp:32-40) and round(32768/LevelScale) (F/quantizationTransform.cpp:24-32)
+__device__ __forceinline__ int level_scale(int m, int i, int j)
+{
+    const int v[6][3] = {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}};
+    int cls = ((i | j) & 1) == 0 ? 0 : ((i & j & 1) ? 1 : 2);
+    return 16 * v[m][cls];
+}
+__device__ __forceinline__ int level_quant(int m, int i, int j)
+{
+    int ls = level_scale(m, i, j);
+    return (65536 + ls) / (2 * ls);
+}
+
+// ---------------------------------------------------------------- 4x4 transforms (one block per lane)
+// a1: F/quantizationTransform.cpp:41-100
+__device__ __forceinline__ void fwd4x4(const int r[16], int d[16])
+{
+    int h[16], f[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) h[i] = r[i] == 0 ? 0 : r[i] * 64 - 32;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int a = h[j], b = h[4 + j], c = h[8 + j], e = h[12 + j];
+        f[j] = (256 * (a + b + c + e) + 512) >> 10;
+        f[4 + j] = (416 * a + 208 * b - 208 * c - 416 * e + 512) >> 10;
+        f[8 + j] = (256 * (a - b - c + e) + 512) >> 10;
+        f[12 + j] = (208 * a - 416 * b + 416 * c - 208 * e + 512) >> 10;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int a = f[4 * i], b = f[4 * i + 1], c = f[4 * i + 2], e = f[4 * i + 3];
+        d[4 * i] = (256 * (a + b + c + e) + 512) >> 10;
+        d[4 * i + 1] = (416 * a + 208 * b - 208 * c - 416 * e + 512) >> 10;
+        d[4 * i + 2] = (256 * (a - b - c + e) + 512) >> 10;
+        d[4 * i + 3] = (208 * a - 416 * b + 416 * c - 208 * e + 512) >> 10;
+    }
+}
+
+// a2: F/quantizationTransform.cpp:183-223
+__device__ __forceinline__ void quant4x4(const int d[16], int c[16], int qP, bool keepDC)
+{
+    int q6 = qP / 6, m = qP % 6;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int lq = level_quant(m, i >> 2, i & 3);
+        int t = qP < 24 ? ((d[i] * (1 << (4 - q6))) - (1 << (3 - q6))) * lq : (d[i] >> (q6 - 4)) * lq;
+        c[i] = (t + 16384) >> 15;
+    }
+    if (keepDC) c[0] = d[0];
+}
+
+// a6 + a7: F/scaleTransform.cpp:308-340, :101-150
+__device__ __forceinline__ void inv4x4(const int c[16], int r[16], int qP, bool keepDC)
+{
+    int d[16], e[16];
+    int q6 = qP / 6, m = qP % 6;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int ls = level_scale(m, i >> 2, i & 3);
+        d[i] = qP >= 24 ? (c[i] * ls) * (1 << (q6 - 4)) : (c[i] * ls + (1 << (3 - q6))) >> (4 - q6);
+    }
+    if (keepDC) d[0] = c[0];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int e0 = d[4 * i] + d[4 * i + 2], e1 = d[4 * i] - d[4 * i + 2];
+        int e2 = (d[4 * i + 1] >> 1) - d[4 * i + 3], e3 = d[4 * i + 1] + (d[4 * i + 3] >> 1);
+        e[4 * i] = e0 + e3;
+        e[4 * i + 1] = e1 + e2;
+        e[4 * i + 2] = e1 - e2;
+        e[4 * i + 3] = e0 - e3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int g0 = e[j] + e[8 + j], g1 = e[j] - e[8 + j];
+        int g2 = (e[4 + j] >> 1) - e[12 + j], g3 = e[4 + j] + (e[12 + j] >> 1);
+        r[j] = (g0 + g3 + 32) >> 6;
+        r[4 + j] = (g1 + g2 + 32) >> 6;
+        r[8 + j] = (g1 - g2 + 32) >> 6;
+        r[12 + j] = (g0 - g3 + 32) >> 6;
+    }
+}
+
+// a3: F/quantizationTransform.cpp:105-152 + :227-260 (in/out raster 4x4)
+__device__ __forceinline__ void fwd_dc_luma(const int f[16], int c[16], int qP)
+{
+    int e[16], t[16];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int g0 = f[j] + f[12 + j], g1 = f[4 + j] + f[8 + j], g2 = f[4 + j] - f[8 + j], g3 = f[j] - f[12 + j];
+        e[j] = g0 + g1;
+        e[4 + j] = g3 + g2;
+        e[8 + j] = g0 - g1;
+        e[12 + j] = g3 - g2;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int d0 = e[4 * i] + e[4 * i + 3], d1 = e[4 * i + 1] + e[4 * i + 2];
+        int d2 = e[4 * i + 1] - e[4 * i + 2], d3 = e[4 * i] - e[4 * i + 3];
+        t[4 * i] = (d0 + d1 + 8) >> 4;
+        t[4 * i + 1] = (d3 + d2 + 8) >> 4;
+        t[4 * i + 2] = (d0 - d1 + 8) >> 4;
+        t[4 * i + 3] = (d3 - d2 + 8) >> 4;
+    }
+    int q6 = qP / 6, ql = level_quant(qP % 6, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int v = qP >= 36 ? (t[i] >> (q6 - 6)) * ql : ((t[i] * (1 << (6 - q6))) - (1 << (5 - q6))) * ql;
+        c[i] = (v + 16384) >> 15;
+    }
+}
+
+// F/scaleTransform.cpp:154-189 + :344-376
+__device__ __forceinline__ void inv_dc_luma(const int c[16], int dcY[16], int qP)
+{
+    int e[16], f[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int d0 = c[4 * i] + c[4 * i + 2], d1 = c[4 * i] - c[4 * i + 2];
+        int d2 = c[4 * i + 1] - c[4 * i + 3], d3 = c[4 * i + 1] + c[4 * i + 3];
+        e[4 * i] = d0 + d3;
+        e[4 * i + 1] = d1 + d2;
+        e[4 * i + 2] = d1 - d2;
+        e[4 * i + 3] = d0 - d3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int g0 = e[j] + e[8 + j], g1 = e[j] - e[8 + j], g2 = e[4 + j] - e[12 + j], g3 = e[4 + j] + e[12 + j];
+        f[j] = g0 + g3;
+        f[4 + j] = g1 + g2;
+        f[8 + j] = g1 - g2;
+        f[12 + j] = g0 - g3;
+    }
+    int q6 = qP / 6, ls = level_scale(qP % 6, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        dcY[i] = qP >= 36 ? (f[i] * ls) * (1 << (q6 - 6)) : (f[i] * ls + (1 << (5 - q6))) >> (6 - q6);
+}
+
+// a4: F/quantizationTransform.cpp:157-178 + :264-282; in/out raster 2x2
+__device__ __forceinline__ void fwd_dc_chroma(const int f[4], int c[4], int qP)
+{
+    int d00 = f[0] + f[1], d01 = f[0] - f[1], d10 = f[2] + f[3], d11 = f[2] - f[3];
+    int t[4] = {(d00 + d10 + 2) >> 2, (d01 + d11 + 2) >> 2, (d00 - d10 + 2) >> 2, (d01 - d11 + 2) >> 2};
+    int q6 = qP / 6, ql = level_quant(qP % 6, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) c[i] = ((((t[i] * 32) >> q6) * ql) + 16384) >> 15;
+}
+
+// F/scaleTransform.cpp:247-261 + :408-421
+__device__ __forceinline__ void inv_dc_chroma(const int c[4], int dc[4], int qP)
+{
+    int d00 = c[0] + c[2], d01 = c[1] + c[3], d10 = c[0] - c[2], d11 = c[1] - c[3];
+    int f[4] = {d00 + d01, d00 - d01, d10 + d11, d10 - d11};
+    int q6 = qP / 6, ls = level_scale(qP % 6, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) dc[i] = ((f[i] * ls) * (1 << q6)) >> 5;
+}
+
+// ---------------------------------------------------------------- motion compensation (a17)
+__device__ __forceinline__ int tap6(int E, int F, int G, int H, int I, int J)
+{
+    return clip255((E - 5 * F + 20 * G + 20 * H - 5 * I + J + 16) >> 5);
+}
+#define FER_MID(a, b) (((a) + (b) + 1) >> 1)
+
+// Quarter-pel sample at integer position (X,Y) of plane R with per-coordinate edge clamping,
+// F/mocomp.cpp:11-36,50-78.  The centre sample j filters clipped intermediates (reference quirk).
+__device__ __forceinline__ int luma_frac_at(const uint8_t *__restrict__ R, int W, int H, int X, int Y, int frac)
+{
+    int xs[6], ys[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        xs[k] = iclamp(X + k - 2, 0, W - 1);
+        ys[k] = iclamp(Y + k - 2, 0, H - 1) * W;
+    }
+#define PXL(dx, dy) ((int)R[ys[(dy) + 2] + xs[(dx) + 2]])
+    int G = PXL(0, 0);
+    if (frac == 0) return G;
+    int b = tap6(PXL(-2, 0), PXL(-1, 0), G, PXL(1, 0), PXL(2, 0), PXL(3, 0));
+    if (frac == 1) return FER_MID(G, b);
+    if (frac == 2) return b;
+    if (frac == 3) return FER_MID(b, PXL(1, 0));
+    int h = tap6(PXL(0, -2), PXL(0, -1), G, PXL(0, 1), PXL(0, 2), PXL(0, 3));
+    if (frac == 4) return FER_MID(G, h);
+    if (frac == 8) return h;
+    if (frac == 12) return FER_MID(h, PXL(0, 1));
+    if (frac == 5) return FER_MID(b, h);
+    int m = tap6(PXL(1, -2), PXL(1, -1), PXL(1, 0), PXL(1, 1), PXL(1, 2), PXL(1, 3));
+    if (frac == 7) return FER_MID(b, m);
+    int s = tap6(PXL(-2, 1), PXL(-1, 1), PXL(0, 1), PXL(1, 1), PXL(2, 1), PXL(3, 1));
+    if (frac == 13) return FER_MID(h, s);
+    if (frac == 15) return FER_MID(s, m);
+    int cc = tap6(PXL(-2, -2), PXL(-2, -1), PXL(-2, 0), PXL(-2, 1), PXL(-2, 2), PXL(-2, 3));
+    int dd = tap6(PXL(-1, -2), PXL(-1, -1), PXL(-1, 0), PXL(-1, 1), PXL(-1, 2), PXL(-1, 3));
+    int ee = tap6(PXL(2, -2), PXL(2, -1), PXL(2, 0), PXL(2, 1), PXL(2, 2), PXL(2, 3));
+    int ff = tap6(PXL(3, -2), PXL(3, -1), PXL(3, 0), PXL(3, 1), PXL(3, 2), PXL(3, 3));
+    int j = tap6(cc, dd, h, m, ee, ff);
+    if (frac == 10) return j;
+    if (frac == 6) return FER_MID(b, j);
+    if (frac == 9) return FER_MID(h, j);
+    if (frac == 14) return FER_MID(j, s);
+    return FER_MID(j, m);  // frac == 11
+#undef PXL
+}
+
+// luma prediction sample (x,y) of the MB at (xP,yP) for a quadrant MV: F/mocomp.cpp:152-177
+__device__ __forceinline__ int mc_luma(const uint8_t *__restrict__ R, int W, int H, int xP, int yP, int x, int y,
+                                       int mvx, int mvy)
+{
+    return luma_frac_at(R, W, H, xP + x + (mvx >> 2), yP + y + (mvy >> 2), (mvy & 3) * 4 + (mvx & 3));
+}
+
+// chroma prediction sample (x,y in 0..7) of the MB: bilinear over the 3x3 patch of the 4x4 luma
+// sub-block that owns it, F/mocomp.cpp:179-194
+__device__ __forceinline__ int mc_chroma(const uint8_t *__restrict__ R, int Wc, int Hc, int xPc, int yPc, int x,
+                                         int y, int mvx, int mvy)
+{
+    int bx = (x >> 1) << 1, by = (y >> 1) << 1;  // origin of the 2x2 chroma block (xAl/2, yAl/2)
+    int cx = xPc + bx + (mvx >> 3), cy = yPc + by + (mvy >> 3);
+    int ox = x & 1, oy = y & 1;
+    int x0 = iclamp(cx + ox, 0, Wc - 1), x1 = iclamp(cx + ox + 1, 0, Wc - 1);
+    int y0 = iclamp(cy + oy, 0, Hc - 1) * Wc, y1 = iclamp(cy + oy + 1, 0, Hc - 1) * Wc;
+    int xl = mvx & 7, yl = mvy & 7;
+    return ((8 - xl) * (8 - yl) * R[y0 + x0] + xl * (8 - yl) * R[y0 + x1] + (8 - xl) * yl * R[y1 + x0] +
+            xl * yl * R[y1 + x1] + 32) >>
+           6;
+}
+
+// ---------------------------------------------------------------- wave helpers
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}

@@ -1,0 +1,596 @@
+// fer_intra.hip -- I-macroblock decision and reconstruction (rows a10, a11, a12 of SURVEY.md 8a):
+// intraPredictionEncoding (F/intra.cpp:949-1110, CPU path) followed by the final
+// quantizationTransform / setCodedBlockPattern of RBSP_encode (F/rbsp_encoding.cpp:194-219).
+//
+// One wavefront owns one macroblock; macroblocks on the anti-diagonal x + 2y are independent
+// (they need the reconstructed left, up, up-left and up-right neighbours), so the host
+// launches this kernel once per diagonal over all streams.  Inside the wavefront:
+//   phase 1  64 lanes = 4 Intra16x16 modes x 16 blocks: cost = sum |quantised coefficients|
+//   phase 2  chroma prediction + residual (lanes 16..23), Intra16x16 trial levels (lanes 0..15),
+//            exact bit count of the trial (27 CAVLC blocks sized one per lane)
+//   phase 3  144 (block, mode) Intra4x4 costs in three rounds of 64 lanes
+//   phase 4  the 16-step reconstruction chain of Intra4x4 (serial by construction)
+//   phase 5  bit count of the Intra4x4 alternative, decision (strictly fewer bits wins)
+//   phase 6  reconstruction + side information of the winner
+#include "fer_cavlc_dev.h"
+#include "fer_internal.h"
+
+#define P4(x, y) (((x) == -1) ? p[(y) + 1] : p[(x) + 5])
+
+// nine Intra4x4 predictors, F/intra.cpp:140-292; p = corner, 4 left, 8 top
+__device__ void pred4x4(int mode, const int p[13], int o[16])
+{
+    switch (mode) {
+    case 0:
+        for (int i = 0; i < 16; i++) o[i] = p[5 + (i & 3)];
+        break;
+    case 1:
+        for (int i = 0; i < 16; i++) o[i] = p[1 + (i >> 2)];
+        break;
+    case 2: {
+        int r = 128;
+        if (p[0] != -1)
+            r = (p[5] + p[6] + p[7] + p[8] + p[1] + p[2] + p[3] + p[4] + 4) >> 3;
+        else if (p[1] != -1)
+            r = (p[1] + p[2] + p[3] + p[4] + 2) >> 2;
+        else if (p[5] != -1)
+            r = (p[5] + p[6] + p[7] + p[8] + 2) >> 2;
+        for (int i = 0; i < 16; i++) o[i] = r;
+        break;
+    }
+    case 3:
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++)
+                o[y * 4 + x] = (x == 3 && y == 3) ? (p[11] + 3 * p[12] + 2) >> 2
+                                                  : (p[5 + x + y] + 2 * p[6 + x + y] + p[7 + x + y] + 2) >> 2;
+        break;
+    case 4:
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) {
+                if (x > y)
+                    o[y * 4 + x] = (P4(x - y - 2, -1) + 2 * P4(x - y - 1, -1) + P4(x - y, -1) + 2) >> 2;
+                else if (x < y)
+                    o[y * 4 + x] = (P4(-1, y - x - 2) + 2 * P4(-1, y - x - 1) + P4(-1, y - x) + 2) >> 2;
+                else
+                    o[y * 4 + x] = (P4(0, -1) + 2 * P4(-1, -1) + P4(-1, 0) + 2) >> 2;
+            }
+        break;
+    case 5:
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) {
+                int z = 2 * x - y, v;
+                if (z >= 0 && (z & 1) == 0)
+                    v = (P4(x - (y >> 1) - 1, -1) + P4(x - (y >> 1), -1) + 1) >> 1;
+                else if (z >= 0)
+                    v = (P4(x - (y >> 1) - 2, -1) + 2 * P4(x - (y >> 1) - 1, -1) + P4(x - (y >> 1), -1) + 2) >> 2;
+                else if (z == -1)
+                    v = (P4(-1, 0) + 2 * P4(-1, -1) + P4(0, -1) + 2) >> 2;
+                else
+                    v = (P4(-1, y - 1) + 2 * P4(-1, y - 2) + P4(-1, y - 3) + 2) >> 2;
+                o[y * 4 + x] = v;
+            }
+        break;
+    case 6:
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) {
+                int z = 2 * y - x, v;
+                if (z >= 0 && (z & 1) == 0)
+                    v = (P4(-1, y - (x >> 1) - 1) + P4(-1, y - (x >> 1)) + 1) >> 1;
+                else if (z >= 0)
+                    v = (P4(-1, y - (x >> 1) - 2) + 2 * P4(-1, y - (x >> 1) - 1) + P4(-1, y - (x >> 1)) + 2) >> 2;
+                else if (z == -1)
+                    v = (P4(-1, 0) + 2 * P4(-1, -1) + P4(0, -1) + 2) >> 2;
+                else
+                    v = (P4(x - 1, -1) + 2 * P4(x - 2, -1) + P4(x - 3, -1) + 2) >> 2;
+                o[y * 4 + x] = v;
+            }
+        break;
+    case 7:
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) {
+                int b = 5 + x + (y >> 1);
+                o[y * 4 + x] = (y & 1) ? (p[b] + 2 * p[b + 1] + p[b + 2] + 2) >> 2 : (p[b] + p[b + 1] + 1) >> 1;
+            }
+        break;
+    default:
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) {
+                int z = x + 2 * y, v;
+                if (z > 5)
+                    v = p[4];
+                else if (z == 5)
+                    v = (p[3] + 3 * p[4] + 2) >> 2;
+                else if ((z & 1) == 0)
+                    v = (P4(-1, y + (x >> 1)) + P4(-1, y + (x >> 1) + 1) + 1) >> 1;
+                else
+                    v = (P4(-1, y + (x >> 1)) + 2 * P4(-1, y + (x >> 1) + 1) + P4(-1, y + (x >> 1) + 2) + 2) >> 2;
+                o[y * 4 + x] = v;
+            }
+        break;
+    }
+}
+
+// LDS picture window of the macroblock: row 0 / column 0 hold the neighbours.
+//   fr[0][0] corner, fr[0][1..16] top, fr[0][17..20] top-right, fr[1..16][0] left, fr[1..16][1..16] MB
+struct IntraLds {
+    int16_t fr[17][24];     // -1 = unavailable
+    int16_t cfr[2][9][12];  // chroma: same layout, 8x8
+    uint8_t predC[2][8][8];
+    int16_t lv4[16][16];    // Intra4x4 luma levels
+    int16_t lv16[16][16];   // Intra16x16 AC levels (15 used)
+    int16_t dc16[16];
+    int16_t cdc[2][4], cac[2][4][16];
+    int dcraw[16];
+    int dcdeq[16];
+    int key4[144];
+    uint8_t tc16[16], tc4[16], tcc[2][4];
+    uint8_t mode4[16], flag4[16];
+};
+
+// fetch p[13] of block blk from the window (F/intra.cpp:294-378)
+__device__ void fetch4(const IntraLds &L, int blk, bool lastcol, int p[13])
+{
+    int x0 = c_bx[blk], y0 = c_by[blk];
+    p[0] = L.fr[y0][x0];
+    for (int i = 0; i < 4; i++) p[1 + i] = L.fr[y0 + 1 + i][x0];
+    for (int i = 0; i < 4; i++) p[5 + i] = L.fr[y0][x0 + 1 + i];
+    if (p[5] == -1) {
+        for (int i = 9; i < 13; i++) p[i] = -1;
+    } else {
+        bool edge = (x0 == 12 && lastcol) || (x0 == 12 && y0 > 0);
+        if (edge || blk == 3 || blk == 11)
+            for (int i = 9; i < 13; i++) p[i] = p[8];
+        else
+            for (int i = 9; i < 13; i++) p[i] = L.fr[y0][x0 + 5 + i - 9];
+    }
+}
+
+__device__ __forceinline__ bool mode4_avail(int m, const int p[13])
+{
+    if ((m == 0 || m == 3 || m == 7) && p[5] == -1) return false;
+    if ((m == 1 || m == 8) && p[1] == -1) return false;
+    if ((m == 4 || m == 5 || m == 6) && p[0] == -1) return false;
+    return true;
+}
+
+// Intra16x16 prediction sample, F/intra.cpp:426-498
+struct P16 {
+    int dc, a, b, c;
+};
+__device__ __forceinline__ int pred16_px(const IntraLds &L, const P16 &q, int mode, int x, int y)
+{
+    if (mode == 0) return L.fr[0][1 + x];
+    if (mode == 1) return L.fr[1 + y][0];
+    if (mode == 2) return q.dc;
+    return clip255((q.a + q.b * (x - 7) + q.c * (y - 7) + 16) >> 5);
+}
+
+// bits of one residual block for the size estimates; internal neighbours come from LDS
+__device__ int nC_local(const FerDev &d, int s, int mb, bool luma, int blk, int plane, const uint8_t *tcl,
+                        const uint8_t tcc[2][4], int cbpL, int cbpC, bool stale_skip)
+{
+    const int *mbt = d.mb_type + (size_t)s * d.nmb;
+    const uint8_t *cbp = d.cbp + (size_t)s * d.nmb * 2;
+    const uint8_t *tc = d.tc + (size_t)s * d.nmb * 24;
+    bool edgeA, edgeB;
+    int bA, bB;
+    if (luma) {
+        edgeA = blk == 0 || blk == 2 || blk == 8 || blk == 10;
+        edgeB = blk == 0 || blk == 1 || blk == 4 || blk == 5;
+        bA = c_nbA[blk];
+        bB = c_nbB[blk];
+    } else {
+        edgeA = blk == 0 || blk == 2;
+        edgeB = blk < 2;
+        bA = c_nbcA[blk];
+        bB = c_nbcB[blk];
+    }
+    bool availA = true, availB = true;
+    int nA = 0, nB = 0;
+    if (edgeA) {
+        if (mb % d.mbw == 0)
+            availA = false;
+        else {
+            int m = mb - 1;
+            bool zero = luma ? ((cbp[m * 2] & (1 << (bA / 4))) == 0) : ((cbp[m * 2 + 1] & 2) == 0);
+            if (!(mbt[m] == FER_P_SKIP || zero)) nA = luma ? tc[m * 24 + bA] : tc[m * 24 + 16 + plane * 4 + bA];
+        }
+    } else {
+        bool zero = luma ? ((cbpL & (1 << (bA / 4))) == 0) : ((cbpC & 2) == 0);
+        if (!(stale_skip || zero)) nA = luma ? tcl[bA] : tcc[plane][bA];
+    }
+    if (edgeB) {
+        if (mb < d.mbw)
+            availB = false;
+        else {
+            int m = mb - d.mbw;
+            bool zero = luma ? ((cbp[m * 2] & (1 << (bB / 4))) == 0) : ((cbp[m * 2 + 1] & 2) == 0);
+            if (!(mbt[m] == FER_P_SKIP || zero)) nB = luma ? tc[m * 24 + bB] : tc[m * 24 + 16 + plane * 4 + bB];
+        }
+    } else {
+        bool zero = luma ? ((cbpL & (1 << (bB / 4))) == 0) : ((cbpC & 2) == 0);
+        if (!(stale_skip || zero)) nB = luma ? tcl[bB] : tcc[plane][bB];
+    }
+    if (availA && availB) return (nA + nB + 1) >> 1;
+    if (availA) return nA;
+    if (availB) return nB;
+    return 0;
+}
+
+__device__ __forceinline__ int ue_len(unsigned v) { return 2 * (31 - __clz((int)(v + 1))) + 1; }
+
+__global__ __launch_bounds__(64) void k_intra_mb(FerDev d, int diag)
+{
+    __shared__ IntraLds L;
+    const int lane = threadIdx.x;
+    const int s = blockIdx.y;
+    if (d.hdr[s * 4 + 3] != 2) return;
+    int y_lo = diag - (d.mbw - 1);
+    y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+    const int mby = y_lo + blockIdx.x, mbx = diag - 2 * mby;
+    if (mby >= d.mbh || mbx < 0 || mbx >= d.mbw) return;
+    const int mb = mby * d.mbw + mbx;
+    const int W = d.W, Wc = d.Wc;
+    uint8_t *Y = d.curY + (size_t)s * d.ysz;
+    uint8_t *Cp[2] = {d.curCb + (size_t)s * d.csz, d.curCr + (size_t)s * d.csz};
+    const int xp = mbx << 4, yp = mby << 4;
+    const bool availL = mbx > 0, availT = mby > 0, lastcol = mbx == d.mbw - 1;
+    const int QPy = d.qp, QPc = d.qpc;
+    const size_t mbi = (size_t)s * d.nmb + mb;
+    const bool stale_skip = d.mb_type[mbi] == FER_P_SKIP;  // mb_type_array entry left by the previous picture
+
+    // ---- load the window
+    for (int i = lane; i < 17 * 21; i += 64) {
+        int r = i / 21, c = i % 21;
+        int gx = xp + c - 1, gy = yp + r - 1;
+        int v = -1;
+        if (gx >= 0 && gy >= 0 && gx < W && (r > 0 ? c <= 16 : true)) v = Y[(size_t)gy * W + gx];
+        if (r > 0 && c > 16) v = -1;
+        L.fr[r][c] = (int16_t)v;
+    }
+    for (int i = lane; i < 2 * 9 * 9; i += 64) {
+        int pl = i / 81, r = (i % 81) / 9, c = i % 9;
+        int gx = xp / 2 + c - 1, gy = yp / 2 + r - 1;
+        L.cfr[pl][r][c] = (int16_t)((gx >= 0 && gy >= 0) ? Cp[pl][(size_t)gy * Wc + gx] : -1);
+    }
+    __syncthreads();
+
+    // ---- Intra16x16 parameters (DC, plane)
+    P16 q16;
+    {
+        int sx = 0, sy = 0, Hh = 0, V = 0;
+        for (int i = 0; i < 16; i++) {
+            sx += L.fr[0][1 + i];
+            sy += L.fr[1 + i][0];
+        }
+        q16.dc = 128;
+        if (availL && availT)
+            q16.dc = (sx + sy + 16) >> 5;
+        else if (availL)
+            q16.dc = (sy + 8) >> 4;
+        else if (availT)
+            q16.dc = (sx + 8) >> 4;
+        for (int i = 0; i <= 7; i++) {
+            Hh += (i + 1) * (L.fr[0][1 + 8 + i] - L.fr[0][1 + 6 - i]);  // p(6-i,-1): i = 7 -> corner fr[0][0]
+            V += (i + 1) * (L.fr[1 + 8 + i][0] - L.fr[1 + 6 - i][0]);
+        }
+        q16.a = (L.fr[16][0] + L.fr[0][16]) << 4;
+        q16.b = (5 * Hh + 32) >> 6;
+        q16.c = (5 * V + 32) >> 6;
+    }
+
+    // ---- phase 1: Intra16x16 mode costs (F/intra.cpp:980-1001)
+    int mode16;
+    {
+        int mode = lane >> 4, blk = lane & 15;
+        int x0 = c_bx[blk], y0 = c_by[blk];
+        int r[16], t[16], qv[16];
+        for (int i = 0; i < 16; i++)
+            r[i] = L.fr[1 + y0 + (i >> 2)][1 + x0 + (i & 3)] - pred16_px(L, q16, mode, x0 + (i & 3), y0 + (i >> 2));
+        fwd4x4(r, t);
+        quant4x4(t, qv, QPy, false);
+        int c = 0;
+        for (int i = 0; i < 16; i++) c += iabs(qv[i]);
+        c += __shfl_xor(c, 1);
+        c += __shfl_xor(c, 2);
+        c += __shfl_xor(c, 4);
+        c += __shfl_xor(c, 8);
+        int best = 0x7fffffff;
+        mode16 = 0;
+        for (int m = 0; m < 4; m++) {
+            int cm = __shfl(c, m * 16);
+            bool ok = !((m == 0 && !availT) || (m == 1 && !availL) || (m == 3 && !(availL && availT)));
+            if (ok && cm < best) {
+                best = cm;
+                mode16 = m;
+            }
+        }
+    }
+    const int chroma_mode = mode16 == 0 ? 2 : (mode16 == 1 ? 1 : (mode16 == 2 ? 0 : 3));
+
+    // ---- phase 2a: chroma prediction (F/intra.cpp:568-767), two samples per lane
+    {
+        int cx = lane & 7, cy = lane >> 3;
+        for (int pl = 0; pl < 2; pl++) {
+            const int16_t(*cf)[12] = L.cfr[pl];
+            int v;
+            if (chroma_mode == 1)
+                v = cf[1 + cy][0];
+            else if (chroma_mode == 2)
+                v = cf[0][1 + cx];
+            else if (chroma_mode == 3) {
+                int Hh = 0, V = 0;
+                for (int i = 0; i <= 3; i++) {
+                    Hh += (i + 1) * (cf[0][1 + 4 + i] - cf[0][1 + 2 - i]);
+                    V += (i + 1) * (cf[1 + 4 + i][0] - cf[1 + 2 - i][0]);
+                }
+                int a = (cf[8][0] + cf[0][8]) << 4, b = (34 * Hh + 32) >> 6, c = (34 * V + 32) >> 6;
+                v = clip255((a + b * (cx - 3) + c * (cy - 3) + 16) >> 5);
+            } else {
+                int x0 = cx & 4, y0 = cy & 4;
+                int sx = 0, sy = 0;
+                for (int i = 0; i < 4; i++) {
+                    sx += cf[0][1 + x0 + i];
+                    sy += cf[1 + y0 + i][0];
+                }
+                v = 128;
+                if ((x0 == 0 && y0 == 0) || (x0 > 0 && y0 > 0)) {
+                    if (availT && availL)
+                        v = (sx + sy + 4) >> 3;
+                    else if (availL)
+                        v = (sy + 2) >> 2;
+                    else if (availT)
+                        v = (sx + 2) >> 2;
+                } else if (x0 > 0 && y0 == 0) {
+                    if (availT)
+                        v = (sx + 2) >> 2;
+                    else if (availL)
+                        v = (sy + 2) >> 2;
+                } else {
+                    if (availL)
+                        v = (sy + 2) >> 2;
+                    else if (availT)
+                        v = (sx + 2) >> 2;
+                }
+            }
+            L.predC[pl][cy][cx] = (uint8_t)v;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2b: chroma residual (lanes 16..23) and the Intra16x16 trial levels (lanes 0..15)
+    const bool isL = lane < 16, isC = lane >= 16 && lane < 24;
+    const int pl = (lane - 16) >> 2, cb = (lane - 16) & 3;
+    int q16v[16];       // quantised Intra16x16 block of this lane (raster), DC slot filled later
+    int crec[16];       // reconstructed chroma block of this lane
+    int cbpC = 0;
+    {
+        int r[16], t[16], qv[16], p[16];
+        int dcr = 0;
+        if (isL) {
+            int x0 = c_bx[lane], y0 = c_by[lane];
+            for (int i = 0; i < 16; i++)
+                r[i] = L.fr[1 + y0 + (i >> 2)][1 + x0 + (i & 3)] - pred16_px(L, q16, mode16, x0 + (i & 3), y0 + (i >> 2));
+            fwd4x4(r, t);
+            quant4x4(t, q16v, QPy, true);
+            L.dcraw[(y0 >> 2) * 4 + (x0 >> 2)] = q16v[0];
+            int cnt = 0;
+            for (int k = 1; k < 16; k++) {
+                int v = q16v[c_zz[k]];
+                L.lv16[lane][k - 1] = (int16_t)v;
+                cnt += v != 0;
+            }
+            L.lv16[lane][15] = 0;
+            L.tc16[lane] = (uint8_t)cnt;
+        } else if (isC) {
+            int x0 = (cb & 1) * 4, y0 = (cb >> 1) * 4;
+            for (int i = 0; i < 16; i++) {
+                p[i] = L.predC[pl][y0 + (i >> 2)][x0 + (i & 3)];
+                r[i] = (int)Cp[pl][(size_t)(yp / 2 + y0 + (i >> 2)) * Wc + xp / 2 + x0 + (i & 3)] - p[i];
+            }
+            fwd4x4(r, t);
+            quant4x4(t, qv, QPc, true);
+            dcr = qv[0];
+        }
+        int base = 16 + (lane >= 20 ? 4 : 0);
+        int f[4], cq[4], dq[4];
+        for (int i = 0; i < 4; i++) f[i] = __shfl(dcr, base + i);
+        fwd_dc_chroma(f, cq, QPc);
+        inv_dc_chroma(cq, dq, QPc);
+        int cnt = 0;
+        if (isC) {
+            L.cdc[pl][cb] = (int16_t)cq[cb];
+            for (int k = 1; k < 16; k++) {
+                int v = qv[c_zz[k]];
+                L.cac[pl][cb][k - 1] = (int16_t)v;
+                cnt += v != 0;
+            }
+            L.cac[pl][cb][15] = 0;
+            L.tcc[pl][cb] = (uint8_t)cnt;
+            qv[0] = dq[cb];
+            inv4x4(qv, r, QPc, true);
+            for (int i = 0; i < 16; i++) crec[i] = clip255(p[i] + r[i]);
+        }
+        unsigned long long acm = __ballot(isC && cnt != 0);
+        unsigned long long dcm = __ballot(isC && cq[cb] != 0);
+        if (dcm) cbpC |= 1;
+        if (acm) cbpC |= 2;
+        if (cbpC == 3) cbpC = 2;
+    }
+    __syncthreads();
+    if (lane == 0) {  // Intra16x16 DC: Hadamard + quantiser (F/quantizationTransform.cpp:105-152,227-260)
+        int f[16], c[16], dq[16];
+        for (int i = 0; i < 16; i++) f[i] = L.dcraw[i];
+        fwd_dc_luma(f, c, QPy);
+        for (int k = 0; k < 16; k++) L.dc16[k] = (int16_t)c[c_zz[k]];
+        inv_dc_luma(c, dq, QPy);
+        for (int i = 0; i < 16; i++) L.dcdeq[i] = dq[i];
+    }
+    __syncthreads();
+    int cbpL16 = 0;
+    for (int b = 0; b < 16; b++)
+        if (L.tc16[b]) cbpL16 = 15;
+
+    // ---- phase 2c: coded_mb_size(mode16) (F/rbsp_encoding.cpp:330-488)
+    int bits16;
+    {
+        int t16 = 1 + mode16 + (cbpC << 2) + (cbpL16 == 15 ? 12 : 0);
+        int hb = ue_len((unsigned)t16) + ue_len((unsigned)chroma_mode) + 1;
+        BitW w;
+        bw_init<false>(w, nullptr, 0, 0);
+        if (lane == 0)
+            cavlc_block<false>(w, L.dc16, 16, nC_local(d, s, mb, true, 0, 0, L.tc16, L.tcc, cbpL16, cbpC, stale_skip));
+        if (lane >= 1 && lane <= 16 && cbpL16)
+            cavlc_block<false>(w, L.lv16[lane - 1], 15,
+                               nC_local(d, s, mb, true, lane - 1, 0, L.tc16, L.tcc, cbpL16, cbpC, stale_skip));
+        if ((lane == 17 || lane == 18) && (cbpC & 3)) cavlc_block<false>(w, L.cdc[lane - 17], 4, -1);
+        if (lane >= 19 && lane < 27 && (cbpC & 2)) {
+            int k = (lane - 19) >> 2, b = (lane - 19) & 3;
+            cavlc_block<false>(w, L.cac[k][b], 15, nC_local(d, s, mb, false, b, k, L.tc16, L.tcc, cbpL16, cbpC, stale_skip));
+        }
+        bits16 = hb + wave_sum((int)w.bits);
+    }
+
+    // ---- phase 3: Intra4x4 mode costs on source samples (F/intra.cpp:1011-1048)
+    for (int rnd = 0; rnd < 3; rnd++) {
+        int task = rnd * 64 + lane;
+        if (task < 144) {
+            int blk = task / 9, mode = task % 9;
+            int p[13], o[16], r[16], t[16], qv[16];
+            fetch4(L, blk, lastcol, p);
+            int key = 0x7fffffff;
+            if (mode4_avail(mode, p)) {
+                pred4x4(mode, p, o);
+                int x0 = c_bx[blk], y0 = c_by[blk];
+                for (int i = 0; i < 16; i++) r[i] = L.fr[1 + y0 + (i >> 2)][1 + x0 + (i & 3)] - o[i];
+                fwd4x4(r, t);
+                quant4x4(t, qv, QPy, false);
+                int c = 0;
+                for (int i = 0; i < 16; i++) c += iabs(qv[i]);
+                key = (c << 4) | mode;
+            }
+            L.key4[task] = key;
+        }
+    }
+    __syncthreads();
+    if (lane < 16) {
+        int best = 0x7fffffff;
+        for (int m = 0; m < 9; m++) best = min(best, L.key4[lane * 9 + m]);
+        L.mode4[lane] = (uint8_t)(best & 15);
+    }
+    __syncthreads();
+
+    // ---- phase 4: Intra4x4 reconstruction chain (F/intra.cpp:1062-1086), serial over the 16 blocks
+    const uint8_t *nmode = d.i4mode + (size_t)s * d.nmb * 16;
+    const int *mbt = d.mb_type + (size_t)s * d.nmb;
+    if (lane == 0) {
+        for (int blk = 0; blk < 16; blk++) {
+            // setIntra4x4PredMode (F/intra.cpp:878-942)
+            bool edgeA = blk == 0 || blk == 2 || blk == 8 || blk == 10;
+            bool edgeB = blk == 0 || blk == 1 || blk == 4 || blk == 5;
+            bool okA = !(edgeA && !availL), okB = !(edgeB && !availT);
+            int mA = 2, mB = 2;
+            if (okA && okB) {
+                if (edgeA) {
+                    int m = mb - 1;
+                    mA = mbt[m] == 0 ? nmode[m * 16 + c_nbA[blk]] : 2;
+                } else
+                    mA = L.mode4[c_nbA[blk]];
+                if (edgeB) {
+                    int m = mb - d.mbw;
+                    mB = mbt[m] == 0 ? nmode[m * 16 + c_nbB[blk]] : 2;
+                } else
+                    mB = L.mode4[c_nbB[blk]];
+            }
+            int pm = mA <= mB ? mA : mB, mode = L.mode4[blk];
+            L.flag4[blk] = (uint8_t)(mode == pm ? 8 : (mode < pm ? mode : mode - 1));
+            int p[13], o[16], r[16], t[16], qv[16];
+            fetch4(L, blk, lastcol, p);
+            pred4x4(mode, p, o);
+            int x0 = c_bx[blk], y0 = c_by[blk];
+            for (int i = 0; i < 16; i++) r[i] = L.fr[1 + y0 + (i >> 2)][1 + x0 + (i & 3)] - o[i];
+            fwd4x4(r, t);
+            quant4x4(t, qv, QPy, false);
+            int cnt = 0;
+            for (int k = 0; k < 16; k++) {
+                int v = qv[c_zz[k]];
+                L.lv4[blk][k] = (int16_t)v;
+                cnt += v != 0;
+            }
+            L.tc4[blk] = (uint8_t)cnt;
+            inv4x4(qv, r, QPy, false);
+            for (int i = 0; i < 16; i++) L.fr[1 + y0 + (i >> 2)][1 + x0 + (i & 3)] = (int16_t)clip255(o[i] + r[i]);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 5: coded_mb_size(-1)
+    int cbpL4 = 0;
+    for (int i8 = 0; i8 < 4; i8++)
+        if (L.tc4[i8 * 4] | L.tc4[i8 * 4 + 1] | L.tc4[i8 * 4 + 2] | L.tc4[i8 * 4 + 3]) cbpL4 |= 1 << i8;
+    int bits4;
+    {
+        int hb = 1;  // ue(I_4x4 = 0)
+        for (int b = 0; b < 16; b++) hb += (L.flag4[b] & 8) ? 1 : 4;
+        hb += ue_len((unsigned)chroma_mode) + ue_len(c_cbp_intra_code[(cbpC << 4) | cbpL4]);
+        BitW w;
+        bw_init<false>(w, nullptr, 0, 0);
+        if (cbpL4 > 0 || cbpC > 0) {
+            hb += 1;
+            if (lane < 16 && (cbpL4 & (1 << (lane >> 2))))
+                cavlc_block<false>(w, L.lv4[lane], 16, nC_local(d, s, mb, true, lane, 0, L.tc4, L.tcc, cbpL4, cbpC, false));
+            if ((lane == 17 || lane == 18) && (cbpC & 3)) cavlc_block<false>(w, L.cdc[lane - 17], 4, -1);
+            if (lane >= 19 && lane < 27 && (cbpC & 2)) {
+                int k = (lane - 19) >> 2, b = (lane - 19) & 3;
+                cavlc_block<false>(w, L.cac[k][b], 15, nC_local(d, s, mb, false, b, k, L.tc4, L.tcc, cbpL4, cbpC, false));
+            }
+        }
+        bits4 = hb + wave_sum((int)w.bits);
+    }
+    const bool use4 = (unsigned)bits4 < (unsigned)bits16;
+
+    // ---- phase 6: reconstruction and side information of the winner
+    int16_t *lv = d.levels + mbi * FER_LEVELS;
+    if (isL) {
+        int x0 = c_bx[lane], y0 = c_by[lane];
+        uint8_t *dst = Y + (size_t)(yp + y0) * W + xp + x0;
+        if (use4) {
+            for (int i = 0; i < 16; i++) dst[(size_t)(i >> 2) * W + (i & 3)] = (uint8_t)L.fr[1 + y0 + (i >> 2)][1 + x0 + (i & 3)];
+            for (int k = 0; k < 16; k++) lv[lane * 16 + k] = L.lv4[lane][k];
+            d.tc[mbi * 24 + lane] = L.tc4[lane];
+        } else {
+            int r[16];
+            q16v[0] = L.dcdeq[(y0 >> 2) * 4 + (x0 >> 2)];
+            inv4x4(q16v, r, QPy, true);
+            for (int i = 0; i < 16; i++)
+                dst[(size_t)(i >> 2) * W + (i & 3)] =
+                    (uint8_t)clip255(pred16_px(L, q16, mode16, x0 + (i & 3), y0 + (i >> 2)) + r[i]);
+            for (int k = 0; k < 16; k++) lv[lane * 16 + k] = L.lv16[lane][k];
+            lv[FER_LV_DC16 + lane] = L.dc16[lane];
+            d.tc[mbi * 24 + lane] = L.tc16[lane];
+        }
+        d.i4mode[mbi * 16 + lane] = L.mode4[lane];
+        d.i4flag[mbi * 16 + lane] = L.flag4[lane];
+    } else if (isC) {
+        int x0 = (cb & 1) * 4, y0 = (cb >> 1) * 4;
+        uint8_t *dst = Cp[pl] + (size_t)(yp / 2 + y0) * Wc + xp / 2 + x0;
+        for (int i = 0; i < 16; i++) dst[(size_t)(i >> 2) * Wc + (i & 3)] = (uint8_t)crec[i];
+        lv[FER_LV_CDC + pl * 4 + cb] = L.cdc[pl][cb];
+        for (int k = 0; k < 15; k++) lv[FER_LV_CAC + (pl * 4 + cb) * 15 + k] = L.cac[pl][cb][k];
+        d.tc[mbi * 24 + lane] = L.tcc[pl][cb];
+    }
+    if (lane == 0) {
+        int cl = use4 ? cbpL4 : cbpL16;
+        d.mb_type[mbi] = use4 ? 0 : 1 + mode16 + (cbpC << 2) + (cl == 15 ? 12 : 0);
+        d.cbp[mbi * 2] = (uint8_t)cl;
+        d.cbp[mbi * 2 + 1] = (uint8_t)cbpC;
+        d.chroma_mode[mbi] = (uint8_t)chroma_mode;
+    }
+}
+
+void fer_launch_intra(const FerDev &d, hipStream_t st)
+{
+    int ndiag = d.mbw + 2 * (d.mbh - 1);
+    int maxk = min(d.mbh, (d.mbw + 1) / 2);
+    for (int dg = 0; dg < ndiag; dg++) hipLaunchKernelGGL(k_intra_mb, dim3(maxk, d.S), dim3(64), 0, st, d, dg);
+}

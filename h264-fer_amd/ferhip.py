@@ -1,0 +1,209 @@
+"""ctypes binding of include/ferhip.h (no torch types cross the C ABI)."""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+NAL_SLICE, NAL_IDR, NAL_AUTO = 1, 5, 0
+
+BUF = dict(INTERP=1, FEAT=2, SORTPOS=3, KOLIKO=4, MBTYPE=5, MV=6, MVD=7, LEVELS=8, CBP=9, TC=10, I4MODE=11,
+           CUR=12, REF=13)
+_BUF_DTYPE = {1: np.uint8, 2: np.uint16, 3: np.uint32, 4: np.int32, 5: np.int32, 6: np.int16, 7: np.int16,
+              8: np.int16, 9: np.uint8, 10: np.uint8, 11: np.uint8, 12: np.uint8, 13: np.uint8}
+
+
+class FerHipError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("qp", C.c_int), ("basic", C.c_int), ("window", C.c_int), ("maxdiff", C.c_int),
+                ("intra_every", C.c_int)]
+
+
+def lib_path():
+    return Path(__file__).resolve().parent / "libferhip.so"
+
+
+_lib = None
+
+
+def load_library():
+    """Load libferhip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not p.exists():
+        raise FerHipError(f"{p} missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    lib = C.CDLL(str(p))
+    vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+    lib.ferhip_version.restype = C.c_char_p
+    lib.ferhip_create.argtypes = [C.POINTER(vp), i, i, i, C.POINTER(Params)]
+    lib.ferhip_destroy.argtypes = [vp]
+    lib.ferhip_destroy.restype = None
+    lib.ferhip_set_frames.argtypes = [vp, vp, i]
+    lib.ferhip_set_reference.argtypes = [vp, vp]
+    lib.ferhip_encode_picture.argtypes = [vp, C.POINTER(i), vp, sz, C.POINTER(C.c_uint32)]
+    lib.ferhip_encode_picture_dev.argtypes = [vp, C.POINTER(i), C.POINTER(vp), C.POINTER(sz), C.POINTER(vp)]
+    lib.ferhip_get_recon.argtypes = [vp, vp, i]
+    lib.ferhip_write_sps.argtypes = [vp, vp, sz]
+    lib.ferhip_write_sps.restype = sz
+    lib.ferhip_write_pps.argtypes = [vp, vp, sz]
+    lib.ferhip_write_pps.restype = sz
+    lib.ferhip_write_nal.argtypes = [i, i, vp, sz, vp]
+    lib.ferhip_write_nal.restype = sz
+    lib.ferhip_encode_streams.argtypes = [vp, vp, i, vp, sz, C.POINTER(sz), vp]
+    lib.ferhip_get_stats.argtypes = [vp, C.POINTER(i)]
+    lib.ferhip_status.argtypes = [vp, C.POINTER(i)]
+    lib.ferhip_fill_interpolated.argtypes = [vp]
+    lib.ferhip_inter_encoding.argtypes = [vp]
+    lib.ferhip_read_buffer.argtypes = [vp, i, vp, sz]
+    lib.ferhip_read_buffer.restype = sz
+    lib.ferhip_forward_residual.argtypes = [i, vp, vp, i, sz]
+    lib.ferhip_inverse_residual.argtypes = [i, vp, vp, i, sz]
+    _lib = lib
+    return lib
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise FerHipError(f"{what} failed with code {rc}")
+
+
+class FerHip:
+    """One encoder context = S independent streams of W x H pictures on one GPU.
+
+    Mirrors Starter::PostaviParametre / PokreniKoder / NastaviKoder / DohvatiStatistiku.
+    """
+
+    def __init__(self, width, height, nstreams=1, qp=12, window=16, maxdiff=3, intra_every=30, basic=0):
+        self.lib = load_library()
+        self.W, self.H, self.S = width, height, nstreams
+        self.nmb = (width // 16) * (height // 16)
+        self.fsz = width * height * 3 // 2
+        self.params = Params(qp, basic, window, maxdiff, intra_every)
+        self.ctx = C.c_void_p()
+        _chk(self.lib.ferhip_create(C.byref(self.ctx), width, height, nstreams, C.byref(self.params)), "ferhip_create")
+
+    def close(self):
+        if self.ctx:
+            self.lib.ferhip_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- pictures
+    def set_frames(self, frames):
+        a = np.ascontiguousarray(frames, dtype=np.uint8).reshape(self.S, self.fsz)
+        _chk(self.lib.ferhip_set_frames(self.ctx, a.ctypes.data, 1), "ferhip_set_frames")
+
+    def set_frames_device(self, dptr):
+        _chk(self.lib.ferhip_set_frames(self.ctx, C.c_void_p(int(dptr)), 0), "ferhip_set_frames(dev)")
+
+    def set_reference(self, frames):
+        a = np.ascontiguousarray(frames, dtype=np.uint8).reshape(self.S, self.fsz)
+        _chk(self.lib.ferhip_set_reference(self.ctx, a.ctypes.data), "ferhip_set_reference")
+
+    def encode_picture(self, nal_types=None):
+        """RBSP_encode for one picture of every stream -> (list of rbsp bytes, nal types)."""
+        nt = (C.c_int * self.S)(*([NAL_AUTO] * self.S if nal_types is None else nal_types))
+        stride = self.nmb * 1024 + 4096
+        buf = np.empty((self.S, stride), np.uint8)
+        ln = (C.c_uint32 * self.S)()
+        _chk(self.lib.ferhip_encode_picture(self.ctx, nt, buf.ctypes.data, stride, ln), "ferhip_encode_picture")
+        return [bytes(buf[s, : ln[s]]) for s in range(self.S)], list(nt)
+
+    def encode_picture_device(self, nal_types=None):
+        nt = (C.c_int * self.S)(*([NAL_AUTO] * self.S if nal_types is None else nal_types))
+        p, st, pl = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        _chk(self.lib.ferhip_encode_picture_dev(self.ctx, nt, C.byref(p), C.byref(st), C.byref(pl)),
+             "ferhip_encode_picture_dev")
+        return p.value, st.value, pl.value, list(nt)
+
+    def get_recon(self):
+        out = np.empty((self.S, self.fsz), np.uint8)
+        _chk(self.lib.ferhip_get_recon(self.ctx, out.ctypes.data, 1), "ferhip_get_recon")
+        return out
+
+    def encode_streams(self, frames, want_recon=False):
+        """frames: [T][S][fsz] uint8 -> (list of Annex-B byte strings, recon or None)."""
+        a = np.ascontiguousarray(frames, dtype=np.uint8)
+        T = a.size // (self.S * self.fsz)
+        a = a.reshape(T, self.S, self.fsz)
+        stride = 64 + T * (self.nmb * 1024 + 4096) * 3 // 2
+        out = np.empty((self.S, stride), np.uint8)
+        ln = (C.c_size_t * self.S)()
+        rec = np.empty((T, self.S, self.fsz), np.uint8) if want_recon else None
+        _chk(self.lib.ferhip_encode_streams(self.ctx, a.ctypes.data, T, out.ctypes.data, stride, ln,
+                                            rec.ctypes.data if want_recon else None), "ferhip_encode_streams")
+        return [bytes(out[s, : ln[s]]) for s in range(self.S)], rec
+
+    def sps_pps(self):
+        b = np.empty(64, np.uint8)
+        o = np.empty(128, np.uint8)
+        n = self.lib.ferhip_write_sps(self.ctx, b.ctypes.data, 64)
+        m = self.lib.ferhip_write_nal(1, 7, b.ctypes.data, n, o.ctypes.data)
+        sps = bytes(o[:m])
+        n = self.lib.ferhip_write_pps(self.ctx, b.ctypes.data, 64)
+        m = self.lib.ferhip_write_nal(1, 8, b.ctypes.data, n, o.ctypes.data)
+        return sps, bytes(o[:m])
+
+    def write_nal(self, nal_type, rbsp):
+        r = np.frombuffer(rbsp, np.uint8)
+        o = np.empty(len(rbsp) * 3 // 2 + 16, np.uint8)
+        m = self.lib.ferhip_write_nal(1, nal_type, r.ctypes.data, len(rbsp), o.ctypes.data)
+        return bytes(o[:m])
+
+    # --- stage entry points / state read-back
+    def fill_interpolated(self):
+        _chk(self.lib.ferhip_fill_interpolated(self.ctx), "ferhip_fill_interpolated")
+
+    def inter_encoding(self):
+        _chk(self.lib.ferhip_inter_encoding(self.ctx), "ferhip_inter_encoding")
+
+    def read(self, name):
+        which = BUF[name]
+        n = self.nmb * self.S
+        px = self.W * self.H * self.S
+        count = {1: px * 16, 2: px * 80, 3: px, 4: 16385 * self.S, 5: n, 6: n * 8, 7: n * 8, 8: n * 400, 9: n * 2,
+                 10: n * 24, 11: n * 16, 12: self.fsz * self.S, 13: self.fsz * self.S}[which]
+        out = np.empty(count, _BUF_DTYPE[which])
+        got = self.lib.ferhip_read_buffer(self.ctx, which, out.ctypes.data, out.nbytes)
+        if got != out.nbytes:
+            raise FerHipError(f"ferhip_read_buffer({name}) returned {got}, expected {out.nbytes}")
+        return out
+
+    def stats(self):
+        a = (C.c_int * (5 * self.S))()
+        _chk(self.lib.ferhip_get_stats(self.ctx, a), "ferhip_get_stats")
+        return np.array(a).reshape(self.S, 5)
+
+    def status(self):
+        a = (C.c_int * self.S)()
+        _chk(self.lib.ferhip_status(self.ctx, a), "ferhip_status")
+        return list(a)
+
+
+def forward_residual(qp, blocks, keep_dc=False):
+    """forwardResidual of F/quantizationTransform.h on n 4x4 int32 blocks (device)."""
+    lib = load_library()
+    a = np.ascontiguousarray(blocks, np.int32).reshape(-1, 16)
+    out = np.empty_like(a)
+    _chk(lib.ferhip_forward_residual(qp, a.ctypes.data, out.ctypes.data, int(keep_dc), a.shape[0]),
+         "ferhip_forward_residual")
+    return out
+
+
+def inverse_residual(qp, blocks, keep_dc=False):
+    lib = load_library()
+    a = np.ascontiguousarray(blocks, np.int32).reshape(-1, 16)
+    out = np.empty_like(a)
+    _chk(lib.ferhip_inverse_residual(qp, a.ctypes.data, out.ctypes.data, int(keep_dc), a.shape[0]),
+         "ferhip_inverse_residual")
+    return out

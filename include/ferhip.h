@@ -1,0 +1,128 @@
+/*
+ * ferhip.h -- C ABI of libferhip, the MI355X-native drop-in for the per-macroblock hot path
+ * of fer_h264 (zoltanmaric/h264-fer).  F/ = fer_h264/fer_h264/ in the reference tree.
+ *
+ * The reference has no plugin/FFI seam: its NAL/slice driver (F/fer_h264.cpp:55-134) calls
+ *     void RBSP_encode(NALunit &nal_unit);      F/rbsp_encoding.h:3, F/rbsp_encoding.cpp:119
+ *     int  selectNALUnitType();                 F/ref_frames.h, F/ref_frames.cpp:185
+ *     void writeNAL(NALunit nu);                F/nal.h:27, F/nal.cpp:261
+ * and communicates through process globals (`frame`, `_qParameter`, `WindowSize`, ...
+ * F/h264_globals.h:152-176).  That makes it one stream per process.  This library exports
+ *   (1) a context-based ABI in which one context carries what those globals carry for S
+ *       independent streams, so that many pictures are in flight on one GPU, and
+ *   (2) the legacy global-state entry points (same names, same argument meaning) as thin
+ *       shims over a one-stream context: see "legacy seam" below and INTEGRATION.md.
+ * All pointers are plain host or device pointers; no C++ or torch types cross the boundary.
+ * Every function returns 0 on success or a negative FERHIP_E_* code; nothing falls back to
+ * a CPU path.
+ */
+#ifndef FERHIP_H
+#define FERHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FERHIP_E_ARG -1     /* bad argument */
+#define FERHIP_E_HIP -2     /* HIP runtime error (no device, out of memory, launch failure) */
+#define FERHIP_E_STATE -3   /* call order violated */
+#define FERHIP_E_UNSUP -4   /* parameter combination the GPU path does not implement */
+#define FERHIP_E_DEVICE -5  /* sticky device-side error flag, see ferhip_status() */
+
+#define FERHIP_NAL_SLICE 1 /* NAL_UNIT_TYPE_NOT_IDR, F/h264_globals.h:84 */
+#define FERHIP_NAL_IDR 5   /* NAL_UNIT_TYPE_IDR */
+#define FERHIP_NAL_AUTO 0  /* decide like selectNALUnitType() */
+
+typedef struct ferhip_ctx ferhip_ctx;
+
+/* Parameters of Starter::PostaviParametre (F/fer_h264.cpp:169-178) minus the frame range. */
+typedef struct {
+    int qp;          /* _qParameter: QPy of every slice, 10..30 in the reference GUI */
+    int basic;       /* BasicInterEncoding; only 0 is implemented on the GPU */
+    int window;      /* WindowSize: +-window/2 integer search, +-window/16 quarter-pel search */
+    int maxdiff;     /* MAXDIFF_SET, -1 = adaptive */
+    int intra_every; /* IntraEvery */
+} ferhip_params;
+
+/* ---- context ---- */
+/* width/height: coded picture size, multiples of 16 (the reference crops to that,
+ * F/fileIO.cpp:242-243).  nstreams: independent streams encoded side by side. */
+int ferhip_create(ferhip_ctx **out, int width, int height, int nstreams, const ferhip_params *p);
+void ferhip_destroy(ferhip_ctx *c);
+
+/* ---- picture input: replaces ReadFromY4M() filling the global `frame` (F/fileIO.cpp:258) ----
+ * I420 pictures of coded size, one per stream, stream-major: [nstreams][W*H*3/2].
+ * host = 1: src is host memory (copied H2D); host = 0: src is a device pointer (D2D). */
+int ferhip_set_frames(ferhip_ctx *c, const void *src, int host);
+
+/* ---- RBSP_encode for slice NAL units (F/rbsp_encoding.cpp:139-323) ----
+ * nal_type[s]: FERHIP_NAL_IDR / FERHIP_NAL_SLICE / FERHIP_NAL_AUTO per stream on input, the
+ * type actually used on output (NULL = AUTO for all).  After the call the picture buffers
+ * hold the reconstruction (like the reference's `frame`) and become the reference picture.
+ * rbsp (host): nstreams * rbsp_stride bytes; rbsp_len[s] receives NumBytesInRBSP. */
+int ferhip_encode_picture(ferhip_ctx *c, int *nal_type, uint8_t *rbsp, size_t rbsp_stride, uint32_t *rbsp_len);
+
+/* Same, but leaves the RBSP in device memory (no D2H): *d_rbsp receives the device base,
+ * words are big-endian bit order, stream s starts at byte s * *stride. */
+int ferhip_encode_picture_dev(ferhip_ctx *c, int *nal_type, const uint8_t **d_rbsp, size_t *stride,
+                              const uint32_t **d_rbsp_len);
+
+/* reconstruction of the last encoded picture, [nstreams][W*H*3/2]; host = 1 copies D2H */
+int ferhip_get_recon(ferhip_ctx *c, void *dst, int host);
+
+/* SPS / PPS RBSP (F/headers_and_parameter_sets.cpp:305-391,478-513) and NAL framing with
+ * emulation prevention (F/nal.cpp:261-299); host-side, byte-serial. */
+size_t ferhip_write_sps(ferhip_ctx *c, uint8_t *rbsp, size_t cap);
+size_t ferhip_write_pps(ferhip_ctx *c, uint8_t *rbsp, size_t cap);
+size_t ferhip_write_nal(int nal_ref_idc, int nal_type, const uint8_t *rbsp, size_t n, uint8_t *out);
+
+/* encode() + NastaviEncode() for S streams of T pictures each (F/fer_h264.cpp:55-134):
+ * frames host [T][S][W*H*3/2]; out host [S][out_stride] Annex-B; out_len[S].
+ * recon (optional) host [T][S][W*H*3/2]. */
+int ferhip_encode_streams(ferhip_ctx *c, const uint8_t *frames, int nframes, uint8_t *out, size_t out_stride,
+                          size_t *out_len, uint8_t *recon);
+
+/* statistics of Starter::DohvatiStatistiku: brojTipova[5] per stream, accumulated */
+int ferhip_get_stats(ferhip_ctx *c, int *counts5_per_stream);
+/* sticky device error flags per stream (bit 0: stage-2 candidate overflow, bit 1: an 8x8
+ * block of the reference picture sums to 0, bit 2: RBSP buffer overflow) */
+int ferhip_status(ferhip_ctx *c, int *flags_per_stream);
+const char *ferhip_version(void);
+
+/* ---- per-stage entry points (unit-parity surface, SURVEY.md 8b "per-MB") ----
+ * They operate on the pictures currently in the context, for all streams. */
+/* FillInterpolatedRefFrame(), F/moestimation.h / F/moestimation.cpp:74 */
+int ferhip_fill_interpolated(ferhip_ctx *c);
+/* motion decision of every MB = interEncoding() over the picture, F/moestimation.cpp:392 */
+int ferhip_inter_encoding(ferhip_ctx *c);
+/* debug/test read-back of device state; which: see FERHIP_BUF_*; returns bytes copied */
+#define FERHIP_BUF_INTERP 1   /* uint8  [S][16][H][W] */
+#define FERHIP_BUF_FEAT 2     /* uint16 [S][16][5][H][W] */
+#define FERHIP_BUF_SORTPOS 3  /* uint32 [S][W*H] */
+#define FERHIP_BUF_KOLIKO 4   /* int32  [S][16385] */
+#define FERHIP_BUF_MBTYPE 5   /* int32  [S][nmb] */
+#define FERHIP_BUF_MV 6       /* int16  [S][nmb][4][2] */
+#define FERHIP_BUF_MVD 7      /* int16  [S][nmb][4][2] */
+#define FERHIP_BUF_LEVELS 8   /* int16  [S][nmb][400] */
+#define FERHIP_BUF_CBP 9      /* uint8  [S][nmb][2] */
+#define FERHIP_BUF_TC 10      /* uint8  [S][nmb][24] */
+#define FERHIP_BUF_I4MODE 11  /* uint8  [S][nmb][16] */
+#define FERHIP_BUF_CUR 12     /* uint8  [S][W*H*3/2] current picture buffers */
+#define FERHIP_BUF_REF 13     /* uint8  [S][W*H*3/2] reference picture buffers */
+size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t cap);
+/* set the reference picture (dpb) directly, [S][W*H*3/2] host */
+int ferhip_set_reference(ferhip_ctx *c, const void *src);
+
+/* ---- block-level KAT surface: the reference's own signatures as batched device calls ----
+ * forwardResidual(qP, c, r, Intra, Intra16x16OrChroma), F/quantizationTransform.h:
+ * n blocks of 16 int32 (raster) in, 16 int32 out. */
+int ferhip_forward_residual(int qP, const int32_t *in, int32_t *out, int keep_dc, size_t nblocks);
+/* inverseResidual(bitDepth, qP, c, r, intra16x16OrChroma), F/scaleTransform.h */
+int ferhip_inverse_residual(int qP, const int32_t *in, int32_t *out, int keep_dc, size_t nblocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -159,6 +159,8 @@ typedef struct fo_ctx {
     int nal_ref_idc;
     int constrained_intra; /* pps.constrained_intra_pred_flag (decoder) */
     int (*ref_idx_l0)[4];
+    /* test hook: MV field of the last picture saved before FillInterpolatedRefFrame clobbers it */
+    int (*dbg_mvx)[4][4], (*dbg_mvy)[4][4];
 } fo_ctx;
 
 fo_ctx *fo_create(int W, int H);

@@ -38,6 +38,8 @@ fo_ctx *fo_create(int W, int H)
     c->mvy = calloc((size_t)c->nmb, sizeof *c->mvy);
     c->refidx = (int *)calloc((size_t)c->nmb, sizeof(int));
     c->ref_idx_l0 = calloc((size_t)c->nmb, sizeof *c->ref_idx_l0);
+    c->dbg_mvx = calloc((size_t)c->nmb, sizeof *c->dbg_mvx);
+    c->dbg_mvy = calloc((size_t)c->nmb, sizeof *c->dbg_mvy);
     /* defaults of F/h264_globals.cpp:217,301-306 and the GUI */
     c->qp = 12;
     c->basic = 0;
@@ -68,6 +70,8 @@ void fo_destroy(fo_ctx *c)
     free(c->mvy);
     free(c->refidx);
     free(c->ref_idx_l0);
+    free(c->dbg_mvx);
+    free(c->dbg_mvy);
     for (int i = 0; i < 16; i++) {
         free(c->interp[i]);
         for (int k = 0; k < 5; k++) free(c->kar[k][i]);
@@ -287,6 +291,8 @@ size_t fo_encode_slice(fo_ctx *c, int nal_type, uint8_t *rbsp, size_t cap)
     }
     if (mb_skip_run > 0) fo_bw_ue(&w, (unsigned)mb_skip_run);
     size_t n = fo_bw_trailing(&w);
+    memcpy(c->dbg_mvx, c->mvx, (size_t)c->nmb * sizeof *c->mvx);
+    memcpy(c->dbg_mvy, c->mvy, (size_t)c->nmb * sizeof *c->mvy);
     dpb_copy(c); /* initialisationProcess + modificationProcess -> frameDeepCopy */
     fo_fill_interpolated(c);
     c->frames_done++;
