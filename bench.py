@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- macroblocks/sec of the 1080p IPPP encode hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 1920x1080 4:2:0
+synthetic input, coded 1920x1072 (the reference crops to multiples of 16), IPPP with
+IntraEvery = 30, qp 12, WindowSize 32 (+-16 integer search, +-2 quarter-pel search),
+MAXDIFF 3, BasicInterEncoding 0.  One "step" = one closed GOP of 30 pictures for every one of
+the S independent streams resident on the GPU (input pictures already in HBM; the RBSP stays in
+HBM).  Ranks (one per GPU) encode disjoint stream sets, no data-path collective: weak scaling.
+
+Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (dominant kernel, live HIP
+event timing from the library's launch stream) and `cpu_baseline` (the CPU oracle, test
+infrastructure, timed on a bounded sample of the same workload on this host).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "tests"))
+
+W, H_IN, H = 1920, 1080, 1072
+GOP = 30
+QP, WINDOW, MAXDIFF = 12, 32, 3
+ME_BYTES_PER_MB = 528          # 256 B current luma + 256 B reference luma + 16 B MVs
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(frames_np, nframes):
+    """CPU oracle (oracle/fo_cli, a bit-exact port, kind 'port') on the first `nframes` pictures
+    of stream 0: one process = one core, like the single-threaded reference."""
+    cli = ROOT / "oracle" / "fo_cli"
+    if not cli.exists():
+        subprocess.run(["make", "-s", "-C", str(ROOT / "oracle"), "fo_cli"], check=True)
+    tmp = Path(os.environ.get("TMPDIR", "/tmp")) / f"ferbench_{os.getpid()}"
+    tmp.mkdir(parents=True, exist_ok=True)
+    src = tmp / "in.yuv"
+    frames_np[:nframes].tofile(src)
+    out = subprocess.run([str(cli), "enc", str(W), str(H), str(nframes), str(QP), str(WINDOW), str(MAXDIFF),
+                          str(GOP), "0", str(src), str(tmp / "out.264")], check=True, capture_output=True, text=True)
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    for f in tmp.iterdir():
+        f.unlink()
+    tmp.rmdir()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("FER_BENCH_STREAMS", "32")))
+    ap.add_argument("--cpu-frames", type=int, default=3, help="pictures of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from conftest import load_pkg
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = load_pkg()
+    from h264_fer_amd.synth import gen_frames_torch
+    S = args.streams
+    # one GOP of distinct content per stream (seed differs per stream and per rank), resident in HBM
+    frames = gen_frames_torch(W, H_IN, GOP, S, dev, seed=1234 + 1000 * rank, noise=2)
+    # centre crop 1080 -> 1072 like ReadFromY4M (F/fileIO.cpp:290-333)
+    ys = W * H_IN
+    Y = frames[:, :, :ys].view(GOP, S, H_IN, W)[:, :, 4:4 + H, :]
+    U = frames[:, :, ys:ys + ys // 4].view(GOP, S, H_IN // 2, W // 2)[:, :, 2:2 + H // 2, :]
+    V = frames[:, :, ys + ys // 4:].view(GOP, S, H_IN // 2, W // 2)[:, :, 2:2 + H // 2, :]
+    frames = torch.cat([Y.reshape(GOP, S, -1), U.reshape(GOP, S, -1), V.reshape(GOP, S, -1)], dim=2).contiguous()
+    torch.cuda.synchronize()
+
+    enc = pkg.FerHip(W, H, S, qp=QP, window=WINDOW, maxdiff=MAXDIFF, intra_every=GOP)
+    fsz = frames.shape[2]
+    nmb = enc.nmb
+
+    def step():
+        for t in range(GOP):
+            enc.set_frames_device(frames[t].data_ptr())
+            enc.encode_picture_device(None)   # AUTO: selectNALUnitType semantics (IDR every GOP)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    enc.get_profile(reset=True)
+    enc.profile(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = enc.get_profile(reset=True)
+    enc.profile(False)
+    status = enc.status()
+    if any(status):
+        raise SystemExit(f"device error flags {status}")
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_mbs = world * S * GOP * nmb * args.steps
+    value = total_mbs / dt
+
+    # roofline of the dominant kernel (by accumulated device time)
+    dom = max(("me_pre", "me_resolve", "intra", "refprep", "cavlc", "p_resid"), key=lambda k: prof[k][0])
+    ms, launches = prof[dom]
+    p_pictures = (GOP - 1) * args.steps
+    units = {"me_pre": S * nmb * p_pictures, "me_resolve": S * nmb * p_pictures, "p_resid": S * nmb * p_pictures,
+             "refprep": S * nmb * p_pictures, "intra": S * nmb * args.steps,
+             "cavlc": S * nmb * GOP * args.steps}[dom]
+    bytes_per_mb = {"me_pre": ME_BYTES_PER_MB, "me_resolve": ME_BYTES_PER_MB, "p_resid": 1152, "refprep": 384 + 16 * 256,
+                    "intra": 768, "cavlc": 800}[dom]
+    avg_launch_s = (ms / 1e3) / max(launches, 1)
+    achieved = (bytes_per_mb * units / max(launches, 1)) / avg_launch_s / 1e9 if ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": {"me_pre": "k_me_pre", "me_resolve": "k_me_resolve", "intra": "k_intra_mb",
+                                           "refprep": "k_interp+k_features+sort", "cavlc": "k_cavlc",
+                                           "p_resid": "k_p_resid"}[dom],
+                "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": launches,
+                "bytes_per_mb": bytes_per_mb,
+                "phase_ms": {k: round(v[0], 2) for k, v in prof.items()}}
+
+    out = None
+    if rank == 0:
+        cpu = None
+        if world == 1 and args.cpu_frames > 0:
+            res = cpu_baseline(frames[:, 0].cpu().numpy(), args.cpu_frames)
+            cpu = {"value": round(res["mb_per_s"], 1), "unit": "macroblocks/s", "cores": 1, "kind": "port",
+                   "sample": f"first {args.cpu_frames} pictures (I+{args.cpu_frames - 1}P) of stream 0, "
+                             f"{res['mbs']} MBs in {res['seconds']:.1f} s, oracle/fo_cli single thread"}
+        out = {"metric": "macroblocks/sec encode (1080p full-search ME) + bit-exact bitstream vs ref",
+               "value": round(value, 1), "unit": "macroblocks/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "1080p IPPP encode, full-search +-16 ME (BASELINE configs[2])",
+                          "coded_size": f"{W}x{H}", "streams_per_gpu": S, "gop": GOP, "qp": QP, "window": WINDOW,
+                          "maxdiff": MAXDIFF, "mbs_per_step": world * S * GOP * nmb,
+                          "parallelism": f"{world} x {S} independent closed-GOP streams"},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    enc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,31 @@ struct ferhip_ctx {
     uint8_t *planes[2];    // two picture sets, swapped after every picture
     int cur_set;
     bool refprep_valid;
+    // live kernel timing with HIP events on the launch stream (bench.py roofline leg)
+    bool prof;
+    struct Span { int phase; hipEvent_t a, b; long launches; };
+    std::vector<Span> spans;
+    double prof_ms[FERHIP_NPHASE];
+    long prof_launches[FERHIP_NPHASE];
+};
+
+struct ProfScope {
+    ferhip_ctx *c;
+    int idx;
+    ProfScope(ferhip_ctx *c_, int phase, long launches) : c(c_), idx(-1)
+    {
+        if (!c->prof) return;
+        ferhip_ctx::Span sp{phase, nullptr, nullptr, launches};
+        hipEventCreate(&sp.a);
+        hipEventCreate(&sp.b);
+        hipEventRecord(sp.a, c->st);
+        c->spans.push_back(sp);
+        idx = (int)c->spans.size() - 1;
+    }
+    ~ProfScope()
+    {
+        if (idx >= 0) hipEventRecord(c->spans[idx].b, c->st);
+    }
 };
 
 static const int k_qpc[52] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
@@ -109,6 +134,7 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     rc |= dalloc(c, &d.feat, d.ysz * 80 * S);
     rc |= dalloc(c, &d.sort_pos, d.ysz * S);
     rc |= dalloc(c, &d.sort_k12, d.ysz * S);
+    rc |= dalloc(c, &d.sort_k34, d.ysz * S);
     rc |= dalloc(c, &d.koliko, (size_t)16385 * S);
     size_t nm = (size_t)d.nmb * S;
     rc |= dalloc(c, &d.mb_type, nm);
@@ -154,6 +180,9 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     c->types.assign(S, 2);
     c->cur_set = 0;
     c->refprep_valid = false;
+    c->prof = false;
+    memset(c->prof_ms, 0, sizeof c->prof_ms);
+    memset(c->prof_launches, 0, sizeof c->prof_launches);
     bind_planes(c);
     *out = c;
     return 0;
@@ -412,7 +441,10 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
         }
     }
     if (need_sad) {
-        fer_launch_frame_sad(d, c->st);
+        {
+            ProfScope ps(c, FERHIP_PH_FRAME_SAD, 1);
+            fer_launch_frame_sad(d, c->st);
+        }
         CK(hipMemcpyAsync(c->h_sad, d.sad, sizeof(unsigned long long) * S, hipMemcpyDeviceToHost, c->st));
         CK(hipStreamSynchronize(c->st));
         for (int s = 0; s < S; s++)
@@ -426,13 +458,33 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
         anyI |= c->types[s] == 2;
     }
     CK(hipMemcpyAsync(d.hdr, c->h_hdr, sizeof(uint32_t) * 4 * S, hipMemcpyHostToDevice, c->st));
+    const int ndiag = d.mbw + 2 * (d.mbh - 1);
     if (anyP) {
-        if (!c->refprep_valid) fer_launch_refprep(d, c->sort, c->types.data(), c->st);
-        fer_launch_me(d, c->st);
-        fer_launch_p_resid(d, c->st);
+        if (!c->refprep_valid) {
+            ProfScope ps(c, FERHIP_PH_REFPREP, 1);
+            fer_launch_refprep(d, c->sort, c->types.data(), c->st);
+        }
+        {
+            ProfScope ps(c, FERHIP_PH_ME_PRE, 1);
+            fer_launch_me_pre(d, c->st);
+        }
+        {
+            ProfScope ps(c, FERHIP_PH_ME_RESOLVE, ndiag);
+            fer_launch_me_resolve(d, c->st);
+        }
+        {
+            ProfScope ps(c, FERHIP_PH_P_RESID, 1);
+            fer_launch_p_resid(d, c->st);
+        }
     }
-    if (anyI) fer_launch_intra(d, c->st);
-    fer_launch_cavlc(d, c->st);
+    if (anyI) {
+        ProfScope ps(c, FERHIP_PH_INTRA, ndiag);
+        fer_launch_intra(d, c->st);
+    }
+    {
+        ProfScope ps(c, FERHIP_PH_CAVLC, 1);
+        fer_launch_cavlc(d, c->st);
+    }
     CK(hipGetLastError());
     // the reconstruction becomes the reference picture (frameDeepCopy, F/ref_frames.cpp:17)
     c->cur_set ^= 1;
@@ -533,6 +585,37 @@ extern "C" int ferhip_status(ferhip_ctx *c, int *out)
     return 0;
 }
 
+extern "C" int ferhip_profile(ferhip_ctx *c, int enable)
+{
+    if (!c) return FERHIP_E_ARG;
+    c->prof = enable != 0;
+    return 0;
+}
+
+extern "C" int ferhip_get_profile(ferhip_ctx *c, double *ms, long *launches, int reset)
+{
+    if (!c || !ms || !launches) return FERHIP_E_ARG;
+    CK(hipStreamSynchronize(c->st));
+    for (auto &sp : c->spans) {
+        float t = 0;
+        CK(hipEventElapsedTime(&t, sp.a, sp.b));
+        c->prof_ms[sp.phase] += t;
+        c->prof_launches[sp.phase] += sp.launches;
+        hipEventDestroy(sp.a);
+        hipEventDestroy(sp.b);
+    }
+    c->spans.clear();
+    for (int i = 0; i < FERHIP_NPHASE; i++) {
+        ms[i] = c->prof_ms[i];
+        launches[i] = c->prof_launches[i];
+    }
+    if (reset) {
+        memset(c->prof_ms, 0, sizeof c->prof_ms);
+        memset(c->prof_launches, 0, sizeof c->prof_launches);
+    }
+    return 0;
+}
+
 // ---- per-stage entry points
 static void set_all_types(ferhip_ctx *c, int slice_type)
 {
@@ -562,7 +645,8 @@ extern "C" int ferhip_inter_encoding(ferhip_ctx *c)
     set_all_types(c, 0);
     if (!c->refprep_valid) fer_launch_refprep(c->d, c->sort, nullptr, c->st);
     c->refprep_valid = true;
-    fer_launch_me(c->d, c->st);
+    fer_launch_me_pre(c->d, c->st);
+    fer_launch_me_resolve(c->d, c->st);
     CK(hipStreamSynchronize(c->st));
     CK(hipGetLastError());
     return 0;

@@ -35,6 +35,7 @@ struct FerDev {
     uint16_t *feat;      // [S][16][5][H][W]
     uint32_t *sort_pos;  // [S][W*H]  (tx << 16) | ty, ordered by (sum, tx, ty)
     uint32_t *sort_k12;  // [S][W*H]  kar1 | kar2 << 16 of that position
+    uint32_t *sort_k34;  // [S][W*H]  kar3 | kar4 << 16 of that position
     int *koliko;         // [S][16385] bucket start offsets
     // per-MB side information (a20)
     int *mb_type;        // [S][nmb]
@@ -372,9 +373,40 @@ __device__ __forceinline__ int mc_chroma(const uint8_t *__restrict__ R, int Wc, 
 }
 
 // ---------------------------------------------------------------- wave helpers
+// DPP (gfx9 row/wave controls) instead of ds_bpermute: the cross-lane steps sit on the critical
+// path of one-wave-per-macroblock code, where LDS-routed shuffles cost ~100 cycles each.
+#define FER_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, false)
+#define DPP_QUAD_XOR1 0xB1   // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E   // quad_perm [2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+#define DPP_WAVE_SHR1 0x138  // lane i <- lane i-1 over the whole wavefront
+
+// sum over each row of 16 lanes, result in every lane of the row
+__device__ __forceinline__ int row16_sum(int v)
+{
+    v += FER_DPP(v, DPP_QUAD_XOR1);
+    v += FER_DPP(v, DPP_QUAD_XOR2);
+    v += FER_DPP(v, DPP_ROW_HALF_MIRROR);
+    v += FER_DPP(v, DPP_ROW_MIRROR);
+    return v;
+}
+// sum over each group of 8 lanes, result in every lane of the group
+__device__ __forceinline__ int oct_sum(int v)
+{
+    v += FER_DPP(v, DPP_QUAD_XOR1);
+    v += FER_DPP(v, DPP_QUAD_XOR2);
+    v += FER_DPP(v, DPP_ROW_HALF_MIRROR);
+    return v;
+}
 __device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v = row16_sum(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+// value of lane `src` (wave-uniform index) in every lane
+__device__ __forceinline__ int lane_bcast(int v, int src)
+{
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));
 }

@@ -12,7 +12,8 @@ struct FerSortTmp {
 size_t fer_sort_tmp_bytes(int n);
 void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStream_t st);
 void fer_launch_frame_sad(const FerDev &d, hipStream_t st);
-void fer_launch_me(const FerDev &d, hipStream_t st);
+void fer_launch_me_pre(const FerDev &d, hipStream_t st);
+void fer_launch_me_resolve(const FerDev &d, hipStream_t st);
 void fer_launch_p_resid(const FerDev &d, hipStream_t st);
 void fer_launch_intra(const FerDev &d, hipStream_t st);
 void fer_launch_cavlc(const FerDev &d, hipStream_t st);

@@ -291,14 +291,11 @@ __global__ __launch_bounds__(64) void k_intra_mb(FerDev d, int diag)
         quant4x4(t, qv, QPy, false);
         int c = 0;
         for (int i = 0; i < 16; i++) c += iabs(qv[i]);
-        c += __shfl_xor(c, 1);
-        c += __shfl_xor(c, 2);
-        c += __shfl_xor(c, 4);
-        c += __shfl_xor(c, 8);
+        c = row16_sum(c);
         int best = 0x7fffffff;
         mode16 = 0;
         for (int m = 0; m < 4; m++) {
-            int cm = __shfl(c, m * 16);
+            int cm = lane_bcast(c, m * 16);
             bool ok = !((m == 0 && !availT) || (m == 1 && !availL) || (m == 3 && !(availL && availT)));
             if (ok && cm < best) {
                 best = cm;

@@ -30,15 +30,15 @@ __device__ __forceinline__ int unp_y(int xy) { return xy >> 16; }
 // insert the valid candidates of this batch in lane (= arrival) order; list keeps K best
 __device__ __forceinline__ void wl_insert(WList &L, int K, int lane, bool valid, int m, int xy)
 {
-    int thr = __shfl(L.m, K - 1);
+    int thr = lane_bcast(L.m, K - 1);
     unsigned long long mask = __ballot(valid && m < thr);
     while (mask) {
         int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
-        int cm = __shfl(m, src), cxy = __shfl(xy, src);
+        int cm = lane_bcast(m, src), cxy = lane_bcast(xy, src);
         int pos = __popcll(__ballot(lane < K && L.m <= cm));
         if (pos < K) {
-            int um = __shfl_up(L.m, 1), uxy = __shfl_up(L.xy, 1);
+            int um = FER_DPP(L.m, DPP_WAVE_SHR1), uxy = FER_DPP(L.xy, DPP_WAVE_SHR1);
             if (lane > pos && lane < K) {
                 L.m = um;
                 L.xy = uxy;
@@ -72,10 +72,7 @@ __device__ __forceinline__ int sad8_rows(const uint8_t *__restrict__ Ps, size_t 
     int s = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) s += iabs(src[j] - (int)R[min(xPi + j, W - 1)]);
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 4);
-    return s;
+    return oct_sum(s);
 }
 
 // ------------------------------------------------------------------ k_me_pre
@@ -153,6 +150,7 @@ __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
     const int *kol = d.koliko + (size_t)s * 16385;
     const uint32_t *spos = d.sort_pos + (size_t)s * ysz;
     const uint32_t *sk12 = d.sort_k12 + (size_t)s * ysz;
+    const uint32_t *sk34 = d.sort_k34 + (size_t)s * ysz;
     int tren = 0;
     if (!d.basic) {
         for (int j = 0; j <= 180; j++) {
@@ -171,7 +169,13 @@ __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
                         tx = ax - sx;
                         ty = ay - sy;
                         ok = iabs(tx) + iabs(ty) < 280 && iabs(q1 - su[1]) < 100 && iabs(q2 - su[2]) < 100;
-                        if (ok) D = feat_dist(Fs, ysz, W, 0, ay, ax, su);
+                        if (ok) {  // feature distance from the sorted payload: k0 == a, no scattered reads
+                            uint32_t r = sk34[k];
+                            int q3 = (int)(r & 0xffff), q4 = (int)(r >> 16);
+                            D = iabs(su[0] - a) + iabs(su[1] - q1) + iabs(su[0] - su[1] - a + q1) + iabs(su[2] - q2) +
+                                iabs(su[0] - su[2] - a + q2) + iabs(su[3] - q3) + iabs(su[0] - su[3] - a + q3) +
+                                iabs(su[4] - q4) + iabs(su[0] - su[4] - a + q4);
+                        }
                     }
                     unsigned long long mk = __ballot(ok);
                     int rank = tren + __popcll(mk & ((1ull << lane) - 1));
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
             int cost = j < cnt ? sad + iabs(cxv - mvpx) + iabs(cyv - mvpy) : 2000000000;
             // ordered first-minimum over the 8 candidates of this round
             for (int g = 0; g < 8; g++) {
-                int cg = __shfl(cost, g * 8), xg = __shfl(cxv, g * 8), yg = __shfl(cyv, g * 8);
+                int cg = lane_bcast(cost, g * 8), xg = lane_bcast(cxv, g * 8), yg = lane_bcast(cyv, g * 8);
                 if (cg < bmin) {
                     bmin = cg;
                     bx = xg;
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
                 int sad = sad8_rows(Ps, ysz, W, H, sx, sy, cxv, cyv, row, src);
                 int cost = j < cnt ? sad + iabs(cxv - mvpx) + iabs(cyv - mvpy) : 2000000000;
                 for (int g = 0; g < 8; g++) {
-                    int cg = __shfl(cost, g * 8), xg = __shfl(cxv, g * 8), yg = __shfl(cyv, g * 8);
+                    int cg = lane_bcast(cost, g * 8), xg = lane_bcast(cxv, g * 8), yg = lane_bcast(cyv, g * 8);
                     if (cg < bmin) {
                         bmin = cg;
                         bx = xg;
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
                 cost = c3[lane * 3 + 2] + iabs(cxv - mvpx) + iabs(cyv - mvpy);
             }
             for (int g = 0; g < n3; g++) {
-                int cg = __shfl(cost, g), xg = __shfl(cxv, g), yg = __shfl(cyv, g);
+                int cg = lane_bcast(cost, g), xg = lane_bcast(cxv, g), yg = lane_bcast(cyv, g);
                 if (cg < bmin) {
                     bmin = cg;
                     bx = xg;
@@ -574,9 +578,13 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
     }
 }
 
-void fer_launch_me(const FerDev &d, hipStream_t st)
+void fer_launch_me_pre(const FerDev &d, hipStream_t st)
 {
     hipLaunchKernelGGL(k_me_pre, dim3(d.nmb * 4, d.S), dim3(64), 0, st, d);
+}
+
+void fer_launch_me_resolve(const FerDev &d, hipStream_t st)
+{
     int ndiag = d.mbw + 2 * (d.mbh - 1);
     int maxk = min(d.mbh, (d.mbw + 1) / 2);
     for (int dg = 0; dg < ndiag; dg++) hipLaunchKernelGGL(k_me_resolve, dim3(maxk, d.S), dim3(64), 0, st, d, dg);

@@ -144,6 +144,7 @@ __global__ void k_sort_finish(FerDev d, int s, const uint16_t *skeys, const uint
         size_t o = (size_t)ty * d.W + tx;
         d.sort_pos[(size_t)s * n + i] = v;
         d.sort_k12[(size_t)s * n + i] = (uint32_t)F0[d.ysz + o] | ((uint32_t)F0[2 * d.ysz + o] << 16);
+        d.sort_k34[(size_t)s * n + i] = (uint32_t)F0[3 * d.ysz + o] | ((uint32_t)F0[4 * d.ysz + o] << 16);
     }
     if (i <= 16384) {  // koliko[a] = number of positions with sum < a
         int lo = 0, hi = n;

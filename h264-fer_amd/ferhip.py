@@ -61,6 +61,8 @@ def load_library():
     lib.ferhip_inter_encoding.argtypes = [vp]
     lib.ferhip_read_buffer.argtypes = [vp, i, vp, sz]
     lib.ferhip_read_buffer.restype = sz
+    lib.ferhip_profile.argtypes = [vp, i]
+    lib.ferhip_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), i]
     lib.ferhip_forward_residual.argtypes = [i, vp, vp, i, sz]
     lib.ferhip_inverse_residual.argtypes = [i, vp, vp, i, sz]
     _lib = lib
@@ -178,6 +180,18 @@ class FerHip:
         if got != out.nbytes:
             raise FerHipError(f"ferhip_read_buffer({name}) returned {got}, expected {out.nbytes}")
         return out
+
+    PHASES = ("refprep", "me_pre", "me_resolve", "p_resid", "intra", "cavlc", "frame_sad")
+
+    def profile(self, enable=True):
+        _chk(self.lib.ferhip_profile(self.ctx, int(enable)), "ferhip_profile")
+
+    def get_profile(self, reset=True):
+        """{phase: (milliseconds, launches)} measured with HIP events on the launch stream."""
+        ms = (C.c_double * 8)()
+        ln = (C.c_long * 8)()
+        _chk(self.lib.ferhip_get_profile(self.ctx, ms, ln, int(reset)), "ferhip_get_profile")
+        return {n: (ms[k], ln[k]) for k, n in enumerate(self.PHASES)}
 
     def stats(self):
         a = (C.c_int * (5 * self.S))()

@@ -74,3 +74,56 @@ def crop_to_mb(frame, W, H):
     U = U[ct >> 1:(ct >> 1) + Hc // 2, cl >> 1:(cl >> 1) + Wc // 2]
     V = V[ct >> 1:(ct >> 1) + Hc // 2, cl >> 1:(cl >> 1) + Wc // 2]
     return np.concatenate([Y.ravel(), U.ravel(), V.ravel()]), Wc, Hc
+
+
+def gen_frames_torch(W, H, n, S, device, seed=1234, noise=2):
+    """Same pictures as gen_frame(), built with torch integer ops on `device`: [n][S][W*H*3/2] uint8.
+
+    Stream s uses seed + s.  int64 arithmetic wraps like uint64; the logical right shifts are
+    emulated with masks."""
+    import torch
+
+    A = 6364136223846793005
+    Cc = 1442695040888963407
+
+    def s64(v):  # python int -> value representable in int64 (two's complement)
+        v &= _M
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lcg(z):
+        return z * A + Cc
+
+    def lsr(z, k):  # logical shift right of an int64 tensor
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    ys = W * H
+    fsz = ys * 3 // 2
+    out = torch.empty((n, S, fsz), dtype=torch.uint8, device=device)
+    y = torch.arange(H, device=device, dtype=torch.int64).view(H, 1)
+    x = torch.arange(W, device=device, dtype=torch.int64).view(1, W)
+    yc = torch.arange(H // 2, device=device, dtype=torch.int64).view(H // 2, 1).expand(H // 2, W // 2)
+    xc = torch.arange(W // 2, device=device, dtype=torch.int64).view(1, W // 2).expand(H // 2, W // 2)
+    idx = y * W + x
+
+    def tri(v, p):
+        m = v % p
+        return torch.where(m < p // 2, m, p - m)
+
+    for s in range(S):
+        sd = seed + s
+        tex = torch.from_numpy(_tex(sd)).to(device)
+        for t in range(n):
+            base = s64(sd ^ ((_G * (t + 1)) & _M))
+            z = idx + base
+            z = lcg(z)
+            z = z ^ lsr(z, 29)
+            z = lcg(z)
+            if noise > 0:
+                nz = lsr(z, 33) % (2 * noise + 1) - noise
+            else:
+                nz = 0
+            v = 40 + tri(x + 2 * t, 192) + tri(y + t, 128) + tex[(y + t) & 63, (x + 2 * t) & 63] + nz
+            out[t, s, :ys] = v.clamp(16, 235).to(torch.uint8).reshape(-1)
+            out[t, s, ys: ys + ys // 4] = (104 + tri(xc + t, 96) // 2).to(torch.uint8).reshape(-1)
+            out[t, s, ys + ys // 4:] = (104 + tri(yc + t, 96) // 2).to(torch.uint8).reshape(-1)
+    return out

@@ -91,6 +91,20 @@ int ferhip_get_stats(ferhip_ctx *c, int *counts5_per_stream);
 int ferhip_status(ferhip_ctx *c, int *flags_per_stream);
 const char *ferhip_version(void);
 
+/* Live kernel timing: when enabled every kernel group of a picture is bracketed by HIP events
+ * on the launch stream.  ferhip_get_profile synchronises and returns accumulated milliseconds
+ * and launch counts per phase. */
+#define FERHIP_PH_REFPREP 0    /* k_interp + k_features + sort */
+#define FERHIP_PH_ME_PRE 1     /* k_me_pre, one launch per picture */
+#define FERHIP_PH_ME_RESOLVE 2 /* k_me_resolve, one launch per MB anti-diagonal */
+#define FERHIP_PH_P_RESID 3    /* k_p_resid */
+#define FERHIP_PH_INTRA 4      /* k_intra_mb, one launch per MB anti-diagonal */
+#define FERHIP_PH_CAVLC 5      /* size + scan + emit */
+#define FERHIP_PH_FRAME_SAD 6
+#define FERHIP_NPHASE 8
+int ferhip_profile(ferhip_ctx *c, int enable);
+int ferhip_get_profile(ferhip_ctx *c, double *ms, long *launches, int reset);
+
 /* ---- per-stage entry points (unit-parity surface, SURVEY.md 8b "per-MB") ----
  * They operate on the pictures currently in the context, for all streams. */
 /* FillInterpolatedRefFrame(), F/moestimation.h / F/moestimation.cpp:74 */

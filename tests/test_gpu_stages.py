@@ -69,3 +69,24 @@ def test_inter_decision_matches_oracle(pkg, fo, window, maxdiff, noise):
     assert g.status() == [0]
     assert np.array_equal(g.read("MBTYPE"), o.mb_type())
     assert np.array_equal(g.read("MV").reshape(-1, 4, 2).astype(np.int32), o.mv())
+
+
+def _streams(pkg, n, S, W=W, H=H, noise=2):
+    # stream s uses seed 1234 + s; frames [T][S][fsz]
+    return np.stack([np.stack([pkg.gen_frame(W, H, t, 1234 + s, noise) for s in range(S)]) for t in range(n)])
+
+
+@pytest.mark.parametrize("intra_every,qp,window,noise", [(1, 12, 16, 2), (30, 12, 16, 2), (30, 28, 32, 2), (3, 20, 16, 0)])
+def test_stream_bytes_match_oracle(pkg, fo, intra_every, qp, window, noise):
+    T, S = 4, 2
+    frames = _streams(pkg, T, S, noise=noise)
+    g = pkg.FerHip(W, H, S, qp=qp, window=window, maxdiff=3, intra_every=intra_every)
+    streams, rec = g.encode_streams(frames, want_recon=True)
+    assert g.status() == [0] * S
+    for s in range(S):
+        o = fo.Oracle(W, H, qp=qp, window=window, maxdiff=3, intra_every=intra_every)
+        ref_bytes, ref_rec = o.encode_stream(frames[:, s])
+        o.close()
+        for t in range(T):
+            assert np.array_equal(rec[t, s], ref_rec[t]), f"recon stream {s} frame {t}"
+        assert streams[s] == ref_bytes, f"bitstream stream {s}: {len(streams[s])} vs {len(ref_bytes)}"
