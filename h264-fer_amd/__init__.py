@@ -8,3 +8,4 @@ There is no CPU fallback: if the library or a GPU is missing, calls raise.
 """
 from .ferhip import FerHip, FerHipError, lib_path, load_library  # noqa: F401
 from .synth import gen_frame, gen_frames, crop_to_mb  # noqa: F401
+from .shard import gops_of_rank, merge_gop_streams, split_nals  # noqa: F401

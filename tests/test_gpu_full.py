@@ -1,0 +1,111 @@
+"""GPU parity at BASELINE.json's configurations, through the C ABI (libferhip.so).
+
+Small cases compare byte for byte with committed golden streams; the full-size cases compare
+with the oracle run on the same seeded input and add size-independent properties: the oracle
+decoder reproduces the GPU reconstruction from the GPU bitstream, streams in a batch do not
+influence each other, and repeated runs are identical.
+"""
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.mark.parametrize("case", ["qcif_i_2f_qp12", "qcif_ippp_4f_qp12_w16", "qcif_ippp_4f_qp28_w32", "qcif_skip_5f_qp12"])
+def test_gpu_matches_committed_goldens(pkg, case):
+    m = json.loads((GOLD / "goldens.json").read_text())[case]
+    frames = np.stack([pkg.gen_frame(m["W"], m["H"], 0 if m.get("static") else t, m["seed"], m["noise"]) for t in range(m["T"])])
+    g = pkg.FerHip(m["W"], m["H"], 1, qp=m["qp"], window=m["window"], maxdiff=m["maxdiff"], intra_every=m["intra_every"])
+    streams, rec = g.encode_streams(frames[:, None], want_recon=True)
+    assert g.status() == [0]
+    assert streams[0] == (GOLD / f"{case}.264").read_bytes()
+    assert hashlib.sha256(rec.tobytes()).hexdigest() == m["recon_sha256"]
+    if "skip" in case:
+        assert g.stats()[0][0] > 0, "the case is meant to contain P_Skip macroblocks"
+
+
+def _check_against_oracle(pkg, fo, W, H, T, S, qp, window, intra_every, noise=2, check_streams=(0,)):
+    frames = np.stack([np.stack([pkg.gen_frame(W, H, t, 1234 + s, noise) for s in range(S)]) for t in range(T)])
+    g = pkg.FerHip(W, H, S, qp=qp, window=window, maxdiff=3, intra_every=intra_every)
+    streams, rec = g.encode_streams(frames, want_recon=True)
+    assert g.status() == [0] * S
+    for s in check_streams:
+        o = fo.Oracle(W, H, qp=qp, window=window, maxdiff=3, intra_every=intra_every)
+        ref, ref_rec = o.encode_stream(frames[:, s])
+        o.close()
+        assert np.array_equal(rec[:, s], ref_rec), f"recon of stream {s}"
+        assert streams[s] == ref, f"bitstream of stream {s}"
+    # property: the oracle DEcoder turns the GPU bitstream back into the GPU reconstruction
+    n, dec, _ = fo.decode_stream_md5(streams[-1])
+    assert n == T
+    ys = W * H
+    for t in range(T):
+        assert np.array_equal(dec[t][:ys], rec[t, S - 1][:ys])
+    g.close()
+    return frames, streams, rec
+
+
+def test_720p_intra_config(pkg, fo):
+    """BASELINE configs[1]: 720p I-frame encode (4x4 transform + quant + CAVLC), bit-exact."""
+    _check_against_oracle(pkg, fo, 1280, 720, 2, 2, qp=12, window=16, intra_every=1, check_streams=(0, 1))
+
+
+def test_720p_intra_qp28(pkg, fo):
+    _check_against_oracle(pkg, fo, 1280, 720, 1, 1, qp=28, window=16, intra_every=1)
+
+
+def test_1080p_ippp_config(pkg, fo):
+    """BASELINE configs[2]: 1080p IPPP, WindowSize 32 (+-16 integer search)."""
+    frames, streams, rec = _check_against_oracle(pkg, fo, 1920, 1072, 3, 2, qp=12, window=32, intra_every=30)
+    # property: batching does not couple streams -- stream 1 alone gives the same bytes
+    g = pkg.FerHip(1920, 1072, 1, qp=12, window=32, maxdiff=3, intra_every=30)
+    alone, _ = g.encode_streams(frames[:, 1:2])
+    assert alone[0] == streams[1]
+    # property: idempotent across contexts
+    g2 = pkg.FerHip(1920, 1072, 1, qp=12, window=32, maxdiff=3, intra_every=30)
+    again, _ = g2.encode_streams(frames[:, 1:2])
+    assert again[0] == alone[0]
+
+
+def test_1080p_qp28(pkg, fo):
+    _check_against_oracle(pkg, fo, 1920, 1072, 2, 1, qp=28, window=32, intra_every=30)
+
+
+def test_4k_ippp_config(pkg, fo):
+    """BASELINE configs[3] picture size (32 400 MBs, beyond the reference's own 10 000-MB arrays)."""
+    _check_against_oracle(pkg, fo, 3840, 2160, 2, 1, qp=28, window=32, intra_every=8)
+
+
+def test_ragged_sizes_and_edges(pkg, fo):
+    """one-MB-wide / one-MB-high pictures and a non-multiple-of-64 width exercise every edge rule"""
+    for (W, H) in [(16, 16), (16, 64), (64, 16), (48, 32), (208, 112)]:
+        _check_against_oracle(pkg, fo, W, H, 3, 1, qp=12, window=16, intra_every=30, noise=1)
+
+
+def test_scene_cut_forces_idr(pkg, fo):
+    """selectNALUnitType: frame SAD above 16/pixel turns a P picture into IDR (F/ref_frames.cpp:210-228)."""
+    W, H = 176, 144
+    a = pkg.gen_frame(W, H, 0, 1, 2)
+    b = pkg.gen_frame(W, H, 1, 1, 2)
+    c = (255 - pkg.gen_frame(W, H, 2, 2, 2)).astype(np.uint8)
+    c[: W * H] = np.clip(c[: W * H].astype(int), 16, 235).astype(np.uint8)
+    frames = np.stack([a, b, c, c])[:, None]
+    g = pkg.FerHip(W, H, 1, qp=12, window=16, maxdiff=3, intra_every=30)
+    streams, rec = g.encode_streams(frames, want_recon=True)
+    o = fo.Oracle(W, H, qp=12, window=16, maxdiff=3, intra_every=30)
+    ref, ref_rec = o.encode_stream(frames[:, 0])
+    assert streams[0] == ref and np.array_equal(rec[:, 0], ref_rec)
+    types = [n[4] & 31 for n in pkg.split_nals(ref)]
+    assert types == [7, 8, 5, 1, 5, 1]
+
+
+def test_bad_arguments_are_rejected(pkg):
+    with pytest.raises(pkg.FerHipError):
+        pkg.FerHip(100, 144, 1)          # not a multiple of 16
+    with pytest.raises(pkg.FerHipError):
+        pkg.FerHip(176, 144, 1, basic=1)  # BasicInterEncoding is not implemented on the GPU
