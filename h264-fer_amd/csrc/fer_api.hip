@@ -421,12 +421,12 @@ static void build_header(ferhip_ctx *c, int s, int nal_type)
     c->types[s] = slice_type;
 }
 
-static int run_picture(ferhip_ctx *c, int *nal_type)
+// selectNALUnitType, F/ref_frames.cpp:185-234: nt[s] in = request (AUTO / IDR / SLICE), out = decision
+static int decide_types(ferhip_ctx *c, const int *nal_type, std::vector<int> &nt)
 {
     FerDev &d = c->d;
     const int S = d.S;
-    // ---- selectNALUnitType, F/ref_frames.cpp:185-234
-    std::vector<int> nt(S);
+    nt.assign(S, 0);
     bool need_sad = false;
     for (int s = 0; s < S; s++) {
         int req = nal_type ? nal_type[s] : FERHIP_NAL_AUTO;
@@ -450,6 +450,26 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
         for (int s = 0; s < S; s++)
             if (nt[s] == -1) nt[s] = c->h_sad[s] > ((unsigned long long)d.nmb << 12) ? FERHIP_NAL_IDR : FERHIP_NAL_SLICE;
     }
+    return 0;
+}
+
+extern "C" int ferhip_select_nal_type(ferhip_ctx *c, int *nal_type_out)
+{
+    if (!c || !nal_type_out) return FERHIP_E_ARG;
+    std::vector<int> nt;
+    int rc = decide_types(c, nullptr, nt);
+    if (rc) return rc;
+    for (int s = 0; s < c->d.S; s++) nal_type_out[s] = nt[s];
+    return 0;
+}
+
+static int run_picture(ferhip_ctx *c, int *nal_type)
+{
+    FerDev &d = c->d;
+    const int S = d.S;
+    std::vector<int> nt;
+    int rc0 = decide_types(c, nal_type, nt);
+    if (rc0) return rc0;
     bool anyP = false, anyI = false;
     for (int s = 0; s < S; s++) {
         build_header(c, s, nt[s]);

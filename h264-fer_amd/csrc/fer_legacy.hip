@@ -1,3 +1,92 @@
-// fer_legacy.hip -- placeholder translation unit for the legacy global-state seam
-// (RBSP_encode / frame / NALunit); filled in by fer_legacy shims.
-#include "fer_internal.h"
+// fer_legacy.hip -- the reference's global-state entry points (include/ferhip_legacy.h) as thin
+// shims over a one-stream context of the context-based ABI.  No hot-path arithmetic here.
+#include "../../include/ferhip.h"
+#include "../../include/ferhip_legacy.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <vector>
+
+extern "C" {
+frame_type frame;
+int _qParameter = 12;       // F/h264_globals.cpp:217
+int BasicInterEncoding = 0; // F/h264_globals.cpp:301-306
+int WindowSize = 16;
+int MAXDIFF_SET = -1;
+int IntraEvery = 30;        // the reference leaves it 0 until PostaviParametre (division by zero at F/ref_frames.cpp:191)
+int currFrameCount = 0;
+int brojTipova[5];
+int vrijeme = 0;
+}
+
+static ferhip_ctx *g_ctx = nullptr;
+static int g_have_dpb = 0;
+
+static int ensure_ctx()
+{
+    if (g_ctx) return 0;
+    ferhip_params p = {_qParameter, BasicInterEncoding, WindowSize, MAXDIFF_SET, IntraEvery > 0 ? IntraEvery : 1};
+    int rc = ferhip_create(&g_ctx, frame.Lwidth, frame.Lheight, 1, &p);
+    if (rc) fprintf(stderr, "RBSP_encode: ferhip_create(%dx%d) failed (%d); there is no CPU fallback\n", frame.Lwidth, frame.Lheight, rc);
+    return rc;
+}
+
+extern "C" void RBSP_encode(NALunit *nu)
+{
+    if (!nu || !nu->rbsp_byte) return;
+    nu->NumBytesInRBSP = 0;
+    if (ensure_ctx()) return;
+    if (nu->nal_unit_type == 7) {
+        nu->NumBytesInRBSP = (unsigned)ferhip_write_sps(g_ctx, nu->rbsp_byte, 500000);
+        return;
+    }
+    if (nu->nal_unit_type == 8) {
+        nu->NumBytesInRBSP = (unsigned)ferhip_write_pps(g_ctx, nu->rbsp_byte, 500000);
+        return;
+    }
+    if (nu->nal_unit_type != 5 && nu->nal_unit_type != 1) return;
+    clock_t t0 = clock();
+    size_t ys = (size_t)frame.Lwidth * frame.Lheight, cs = ys / 4;
+    std::vector<unsigned char> pic(ys + 2 * cs);
+    memcpy(pic.data(), frame.L, ys);
+    memcpy(pic.data() + ys, frame.C[0], cs);
+    memcpy(pic.data() + ys + cs, frame.C[1], cs);
+    int type = (int)nu->nal_unit_type;
+    uint32_t len = 0;
+    size_t cap = (size_t)(frame.Lwidth / 16) * (frame.Lheight / 16) * 1024 + 4096;  // the library's own RBSP capacity
+    std::vector<unsigned char> rbsp(cap);
+    int before[5], after[5];
+    ferhip_get_stats(g_ctx, before);
+    int rc = ferhip_set_frames(g_ctx, pic.data(), 1);
+    if (!rc) rc = ferhip_encode_picture(g_ctx, &type, rbsp.data(), cap, &len);
+    if (!rc) rc = ferhip_get_recon(g_ctx, pic.data(), 1);
+    if (rc) {
+        fprintf(stderr, "RBSP_encode: GPU encode failed (%d)\n", rc);
+        return;
+    }
+    memcpy(nu->rbsp_byte, rbsp.data(), len);  // the caller owns rbsp_byte and its size, as in the reference
+    nu->NumBytesInRBSP = len;
+    memcpy(frame.L, pic.data(), ys);  // `frame` now holds the reconstruction (F/inttransform.cpp:62-131)
+    memcpy(frame.C[0], pic.data() + ys, cs);
+    memcpy(frame.C[1], pic.data() + ys + cs, cs);
+    ferhip_get_stats(g_ctx, after);
+    for (int i = 0; i < 5; i++) brojTipova[i] += after[i] - before[i];
+    g_have_dpb = 1;
+    vrijeme = (int)(clock() - t0);
+}
+
+// selectNALUnitType of F/ref_frames.cpp:185-234 on the picture currently in `frame`: the frame SAD
+// against the reference picture is evaluated on the device.
+extern "C" int selectNALUnitType(void)
+{
+    if (!g_have_dpb || ensure_ctx()) return 5;
+    size_t ys = (size_t)frame.Lwidth * frame.Lheight, cs = ys / 4;
+    std::vector<unsigned char> pic(ys + 2 * cs);
+    memcpy(pic.data(), frame.L, ys);
+    memcpy(pic.data() + ys, frame.C[0], cs);
+    memcpy(pic.data() + ys + cs, frame.C[1], cs);
+    int type = 5;
+    if (ferhip_set_frames(g_ctx, pic.data(), 1) || ferhip_select_nal_type(g_ctx, &type)) return 5;
+    return type;
+}

@@ -47,6 +47,7 @@ def load_library():
     lib.ferhip_set_reference.argtypes = [vp, vp]
     lib.ferhip_encode_picture.argtypes = [vp, C.POINTER(i), vp, sz, C.POINTER(C.c_uint32)]
     lib.ferhip_encode_picture_dev.argtypes = [vp, C.POINTER(i), C.POINTER(vp), C.POINTER(sz), C.POINTER(vp)]
+    lib.ferhip_select_nal_type.argtypes = [vp, C.POINTER(i)]
     lib.ferhip_get_recon.argtypes = [vp, vp, i]
     lib.ferhip_write_sps.argtypes = [vp, vp, sz]
     lib.ferhip_write_sps.restype = sz

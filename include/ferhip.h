@@ -64,6 +64,11 @@ int ferhip_set_frames(ferhip_ctx *c, const void *src, int host);
  * rbsp (host): nstreams * rbsp_stride bytes; rbsp_len[s] receives NumBytesInRBSP. */
 int ferhip_encode_picture(ferhip_ctx *c, int *nal_type, uint8_t *rbsp, size_t rbsp_stride, uint32_t *rbsp_len);
 
+/* selectNALUnitType() (F/ref_frames.cpp:185-234) for the pictures set by ferhip_set_frames: IDR for the
+ * first picture, every IntraEvery-th picture and when the luma SAD against the reference picture
+ * exceeds 16 per pixel (evaluated on the device); writes FERHIP_NAL_IDR / FERHIP_NAL_SLICE per stream. */
+int ferhip_select_nal_type(ferhip_ctx *c, int *nal_type_out);
+
 /* Same, but leaves the RBSP in device memory (no D2H): *d_rbsp receives the device base,
  * words are big-endian bit order, stream s starts at byte s * *stride. */
 int ferhip_encode_picture_dev(ferhip_ctx *c, int *nal_type, const uint8_t **d_rbsp, size_t *stride,

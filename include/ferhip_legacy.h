@@ -1,0 +1,55 @@
+/*
+ * ferhip_legacy.h -- the reference's own global-state seam, exported by libferhip with C linkage.
+ *
+ * A maintainer of fer_h264 who wants the GPU path behind the existing NAL/slice driver
+ * (encode()/NastaviEncode(), F/fer_h264.cpp:55-134) links libferhip instead of compiling
+ * rbsp_encoding.cpp, intra.cpp, moestimation.cpp, mocomp.cpp, mode_pred.cpp,
+ * quantizationTransform.cpp, scaleTransform.cpp, inttransform.cpp, residual.cpp and ref_frames.cpp.
+ * Names, argument meaning and side effects are the reference's:
+ *
+ *   reference (C++ linkage)                          here (C linkage)
+ *   void RBSP_encode(NALunit &nal_unit)              void RBSP_encode(NALunit *nal_unit)     F/rbsp_encoding.h:3
+ *   int  selectNALUnitType()                         int  selectNALUnitType(void)            F/ref_frames.cpp:185
+ *   frame_type frame                                 frame_type frame                        F/h264_globals.h:152-158
+ *   int _qParameter, BasicInterEncoding, WindowSize, MAXDIFF_SET, IntraEvery, currFrameCount
+ *                                                                                            F/h264_globals.h:168-176,193
+ *   int brojTipova[5], vrijeme                                                               F/h264_globals.h:166-167
+ *
+ * Contract kept from F/rbsp_encoding.cpp:119-326: nal_unit_type 7 / 8 write SPS / PPS (the SPS
+ * call also sizes the encoder from frame.Lwidth x frame.Lheight); 5 / 1 encode the picture in
+ * `frame` (tightly packed planes), overwrite `frame` with the reconstruction and make it the
+ * reference picture; rbsp_byte is caller-allocated and NumBytesInRBSP is the out-length.
+ * Errors cannot be returned through this signature (the reference returns void): on failure
+ * NumBytesInRBSP is set to 0 and a message goes to stderr.  One stream per process, like the
+ * reference.
+ */
+#ifndef FERHIP_LEGACY_H
+#define FERHIP_LEGACY_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    unsigned char forbidden_zero_bit; /* bool in the reference (F/nal.h:8-14) */
+    unsigned int nal_ref_idc, nal_unit_type, NumBytesInRBSP;
+    unsigned char *rbsp_byte;
+} NALunit;
+
+typedef struct {
+    int Lwidth, Lheight;
+    int Cwidth, Cheight;
+    unsigned char *L, *C[2];
+} frame_type;
+
+extern frame_type frame;
+extern int _qParameter, BasicInterEncoding, WindowSize, MAXDIFF_SET, IntraEvery, currFrameCount;
+extern int brojTipova[5];
+extern int vrijeme; /* clock() ticks spent in the last picture */
+
+void RBSP_encode(NALunit *nal_unit);
+int selectNALUnitType(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

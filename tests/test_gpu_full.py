@@ -109,3 +109,57 @@ def test_bad_arguments_are_rejected(pkg):
         pkg.FerHip(100, 144, 1)          # not a multiple of 16
     with pytest.raises(pkg.FerHipError):
         pkg.FerHip(176, 144, 1, basic=1)  # BasicInterEncoding is not implemented on the GPU
+
+
+def test_legacy_global_seam_matches_oracle(pkg, fo):
+    """Drive the reference's own entry points (RBSP_encode, selectNALUnitType, global `frame`)
+    exactly like encode()/NastaviEncode() do (F/fer_h264.cpp:55-134)."""
+    import ctypes as C
+    lib = pkg.load_library()
+
+    class NALunit(C.Structure):
+        _fields_ = [("forbidden_zero_bit", C.c_ubyte), ("nal_ref_idc", C.c_uint), ("nal_unit_type", C.c_uint),
+                    ("NumBytesInRBSP", C.c_uint), ("rbsp_byte", C.POINTER(C.c_ubyte))]
+
+    class Frame(C.Structure):
+        _fields_ = [("Lwidth", C.c_int), ("Lheight", C.c_int), ("Cwidth", C.c_int), ("Cheight", C.c_int),
+                    ("L", C.POINTER(C.c_ubyte)), ("C", C.POINTER(C.c_ubyte) * 2)]
+
+    W, H, T = 64, 48, 4
+    frame = Frame.in_dll(lib, "frame")
+    for name, v in (("_qParameter", 12), ("BasicInterEncoding", 0), ("WindowSize", 16), ("MAXDIFF_SET", 3), ("IntraEvery", 30)):
+        C.c_int.in_dll(lib, name).value = v
+    ys = W * H
+    L = (C.c_ubyte * ys)()
+    Cb = (C.c_ubyte * (ys // 4))()
+    Cr = (C.c_ubyte * (ys // 4))()
+    frame.Lwidth, frame.Lheight, frame.Cwidth, frame.Cheight = W, H, W // 2, H // 2
+    frame.L = C.cast(L, C.POINTER(C.c_ubyte))
+    frame.C[0] = C.cast(Cb, C.POINTER(C.c_ubyte))
+    frame.C[1] = C.cast(Cr, C.POINTER(C.c_ubyte))
+    buf = (C.c_ubyte * 500000)()
+    nu = NALunit(0, 1, 7, 0, C.cast(buf, C.POINTER(C.c_ubyte)))
+    lib.RBSP_encode.argtypes = [C.POINTER(NALunit)]
+    lib.RBSP_encode.restype = None
+    out = bytearray()
+    g = pkg.FerHip(16, 16, 1)  # only for write_nal()
+    for t in (7, 8):
+        nu.nal_unit_type = t
+        lib.RBSP_encode(C.byref(nu))
+        out += g.write_nal(t, bytes(buf[: nu.NumBytesInRBSP]))
+    frames = np.stack([pkg.gen_frame(W, H, t, 21, 2) for t in range(T)])
+    recs = []
+    for t in range(T):
+        C.c_int.in_dll(lib, "currFrameCount").value = t
+        C.memmove(L, frames[t][:ys].ctypes.data, ys)
+        C.memmove(Cb, frames[t][ys: ys + ys // 4].ctypes.data, ys // 4)
+        C.memmove(Cr, frames[t][ys + ys // 4:].ctypes.data, ys // 4)
+        nu.nal_unit_type = lib.selectNALUnitType()
+        lib.RBSP_encode(C.byref(nu))
+        assert nu.NumBytesInRBSP > 0
+        out += g.write_nal(nu.nal_unit_type, bytes(buf[: nu.NumBytesInRBSP]))
+        recs.append(np.concatenate([np.frombuffer(L, np.uint8), np.frombuffer(Cb, np.uint8), np.frombuffer(Cr, np.uint8)]).copy())
+    o = fo.Oracle(W, H, qp=12, window=16, maxdiff=3, intra_every=30)
+    ref, ref_rec = o.encode_stream(frames)
+    assert bytes(out) == ref
+    assert np.array_equal(np.stack(recs), ref_rec)
