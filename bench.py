@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("FER_BENCH_STREAMS", "32")))
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("FER_BENCH_CONTEXTS", "2")),
+                    help="encoder contexts per GPU, each on its own HIP stream and host thread (streams are split evenly)")
     ap.add_argument("--cpu-frames", type=int, default=3, help="pictures of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -86,14 +88,34 @@ def main():
     frames = torch.cat([Y.reshape(GOP, S, -1), U.reshape(GOP, S, -1), V.reshape(GOP, S, -1)], dim=2).contiguous()
     torch.cuda.synchronize()
 
-    enc = pkg.FerHip(W, H, S, qp=QP, window=WINDOW, maxdiff=MAXDIFF, intra_every=GOP)
-    fsz = frames.shape[2]
+    # The streams are split over `contexts` encoder contexts, each with its own HIP stream and host
+    # thread: while one context sits in its latency-bound per-diagonal launches, the other fills the
+    # CUs with its throughput-bound kernels (the streams are independent, so this is pure overlap).
+    import threading
+    NC = max(1, min(args.contexts, S))
+    bounds = [S * i // NC for i in range(NC + 1)]
+    parts = [frames[:, bounds[i]:bounds[i + 1]].contiguous() for i in range(NC)]
+    del frames
+    torch.cuda.synchronize()
+    encs = [pkg.FerHip(W, H, bounds[i + 1] - bounds[i], qp=QP, window=WINDOW, maxdiff=MAXDIFF, intra_every=GOP)
+            for i in range(NC)]
+    enc = encs[0]
     nmb = enc.nmb
 
-    def step():
+    def run_ctx(i):
+        e, fr = encs[i], parts[i]
         for t in range(GOP):
-            enc.set_frames_device(frames[t].data_ptr())
-            enc.encode_picture_device(None)   # AUTO: selectNALUnitType semantics (IDR every GOP)
+            e.set_frames_device(fr[t].data_ptr())
+            e.encode_picture_device(None)   # AUTO: selectNALUnitType semantics (IDR every GOP)
+
+    def step():
+        if NC == 1:
+            return run_ctx(0)
+        th = [threading.Thread(target=run_ctx, args=(i,)) for i in range(NC)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
 
     def sync():
         torch.cuda.synchronize()
@@ -103,17 +125,23 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    enc.get_profile(reset=True)
-    enc.profile(True)
+    for e in encs:
+        e.get_profile(reset=True)
+        e.profile(True)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     dt = time.perf_counter() - t0
-    prof = enc.get_profile(reset=True)
-    enc.profile(False)
-    status = enc.status()
+    prof = {}
+    status = []
+    for e in encs:
+        for k, (ms_, n_) in e.get_profile(reset=True).items():
+            a = prof.get(k, (0.0, 0))
+            prof[k] = (a[0] + ms_, a[1] + n_)
+        e.profile(False)
+        status += e.status()
     if any(status):
         raise SystemExit(f"device error flags {status}")
     if world > 1:
@@ -128,6 +156,7 @@ def main():
     dom = max(("me_pre", "me_resolve", "intra", "refprep", "cavlc", "p_resid"), key=lambda k: prof[k][0])
     ms, launches = prof[dom]
     p_pictures = (GOP - 1) * args.steps
+    # accumulated over contexts: `launches` counts every context's launches, units all streams
     units = {"me_pre": S * nmb * p_pictures, "me_resolve": S * nmb * p_pictures, "p_resid": S * nmb * p_pictures,
              "refprep": S * nmb * p_pictures, "intra": S * nmb * args.steps,
              "cavlc": S * nmb * GOP * args.steps}[dom]
@@ -148,7 +177,7 @@ def main():
     if rank == 0:
         cpu = None
         if world == 1 and args.cpu_frames > 0:
-            res = cpu_baseline(frames[:, 0].cpu().numpy(), args.cpu_frames)
+            res = cpu_baseline(parts[0][:, 0].cpu().numpy(), args.cpu_frames)
             cpu = {"value": round(res["mb_per_s"], 1), "unit": "macroblocks/s", "cores": 1, "kind": "port",
                    "sample": f"first {args.cpu_frames} pictures (I+{args.cpu_frames - 1}P) of stream 0, "
                              f"{res['mbs']} MBs in {res['seconds']:.1f} s, oracle/fo_cli single thread"}
@@ -157,12 +186,13 @@ def main():
                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "config": {"workload": "1080p IPPP encode, full-search +-16 ME (BASELINE configs[2])",
-                          "coded_size": f"{W}x{H}", "streams_per_gpu": S, "gop": GOP, "qp": QP, "window": WINDOW,
+                          "coded_size": f"{W}x{H}", "streams_per_gpu": S, "contexts_per_gpu": NC, "gop": GOP, "qp": QP, "window": WINDOW,
                           "maxdiff": MAXDIFF, "mbs_per_step": world * S * GOP * nmb,
                           "parallelism": f"{world} x {S} independent closed-GOP streams"},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
-    enc.close()
+    for e in encs:
+        e.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -123,6 +123,7 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     d.window = p->window;
     d.maxdiff_set = p->maxdiff;
     d.basic = 0;
+    d.dbg = getenv("FER_DBG") ? atoi(getenv("FER_DBG")) : 0;
     d.ysz = (size_t)W * H;
     d.csz = d.ysz / 4;
     CK(hipStreamCreate(&c->st));
@@ -131,7 +132,8 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     rc |= dalloc(c, &c->planes[0], fsz * S);
     rc |= dalloc(c, &c->planes[1], fsz * S);
     rc |= dalloc(c, &d.interp, d.ysz * 16 * S);
-    rc |= dalloc(c, &d.feat, d.ysz * 80 * S);
+    rc |= dalloc(c, &d.feat, d.ysz * 96 * S);
+    rc |= dalloc(c, &d.feat0, d.ysz * 6 * S);
     rc |= dalloc(c, &d.sort_pos, d.ysz * S);
     rc |= dalloc(c, &d.sort_k12, d.ysz * S);
     rc |= dalloc(c, &d.sort_k34, d.ysz * S);
@@ -160,11 +162,12 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     rc |= dalloc(c, &d.sad, (size_t)S);
     rc |= dalloc(c, &d.stats, (size_t)5 * S);
     int n = W * H;
-    c->sort.tmp_bytes = fer_sort_tmp_bytes(n);
-    rc |= dalloc(c, &c->sort.keys_in, (size_t)n);
-    rc |= dalloc(c, &c->sort.keys_out, (size_t)n);
-    rc |= dalloc(c, &c->sort.vals_in, (size_t)n);
-    rc |= dalloc(c, &c->sort.vals_out, (size_t)n);
+    c->sort.tmp_bytes = fer_sort_tmp_bytes(n, S);
+    rc |= dalloc(c, &c->sort.keys_in, (size_t)n * S);
+    rc |= dalloc(c, &c->sort.keys_out, (size_t)n * S);
+    rc |= dalloc(c, &c->sort.vals_in, (size_t)n * S);
+    rc |= dalloc(c, &c->sort.vals_out, (size_t)n * S);
+    rc |= dalloc(c, &c->sort.seg_begin, (size_t)S + 1);
     uint8_t *tmp = nullptr;
     rc |= dalloc(c, &tmp, c->sort.tmp_bytes);
     c->sort.tmp = tmp;
@@ -176,6 +179,11 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     CK(hipHostMalloc((void **)&c->h_len, sizeof(uint32_t) * S));
     CK(hipHostMalloc((void **)&c->h_status, sizeof(int) * S));
     CK(hipHostMalloc((void **)&c->h_sad, sizeof(unsigned long long) * S));
+    {
+        std::vector<unsigned> seg(S + 1);
+        for (int i = 0; i <= S; i++) seg[i] = (unsigned)((size_t)i * n);
+        CK(hipMemcpy(c->sort.seg_begin, seg.data(), sizeof(unsigned) * (S + 1), hipMemcpyHostToDevice));
+    }
     c->ss.assign(S, StreamState{0, 0, 0, 0, 0, 0});
     c->types.assign(S, 2);
     c->cur_set = 0;
@@ -489,7 +497,7 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
             fer_launch_me_pre(d, c->st);
         }
         {
-            ProfScope ps(c, FERHIP_PH_ME_RESOLVE, ndiag);
+            ProfScope ps(c, FERHIP_PH_ME_RESOLVE, fer_me_resolve_launches(d));
             fer_launch_me_resolve(d, c->st);
         }
         {
@@ -665,8 +673,14 @@ extern "C" int ferhip_inter_encoding(ferhip_ctx *c)
     set_all_types(c, 0);
     if (!c->refprep_valid) fer_launch_refprep(c->d, c->sort, nullptr, c->st);
     c->refprep_valid = true;
-    fer_launch_me_pre(c->d, c->st);
-    fer_launch_me_resolve(c->d, c->st);
+    {
+        ProfScope ps(c, FERHIP_PH_ME_PRE, 1);
+        fer_launch_me_pre(c->d, c->st);
+    }
+    {
+        ProfScope ps(c, FERHIP_PH_ME_RESOLVE, fer_me_resolve_launches(c->d));
+        fer_launch_me_resolve(c->d, c->st);
+    }
     CK(hipStreamSynchronize(c->st));
     CK(hipGetLastError());
     return 0;
@@ -681,7 +695,7 @@ extern "C" size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t
     size_t n = 0;
     switch (which) {
     case FERHIP_BUF_INTERP: src = d.interp; n = d.ysz * 16 * d.S; break;
-    case FERHIP_BUF_FEAT: src = d.feat; n = d.ysz * 80 * d.S * 2; break;
+    case FERHIP_BUF_FEAT: src = d.feat; n = d.ysz * 96 * d.S * 2; break;
     case FERHIP_BUF_SORTPOS: src = d.sort_pos; n = d.ysz * d.S * 4; break;
     case FERHIP_BUF_KOLIKO: src = d.koliko; n = (size_t)16385 * d.S * 4; break;
     case FERHIP_BUF_MBTYPE: src = d.mb_type; n = nm * 4; break;

@@ -26,13 +26,15 @@
 struct FerDev {
     int W, H, Wc, Hc, mbw, mbh, nmb, S;
     int qp, qpc, window, maxdiff_set, basic;
+    int dbg;  // development only (env FER_DBG): bit mask that skips kernel stages for timing; 0 in production
     size_t ysz, csz;
     // pictures: cur = `frame` (source in, reconstruction out), ref = `dpb`
     uint8_t *curY, *curCb, *curCr;
     uint8_t *refY, *refCb, *refCr;
     // a16: 16 quarter-pel planes, 5 box features per plane, positions sorted by 8x8 sum
     uint8_t *interp;     // [S][16][H][W]
-    uint16_t *feat;      // [S][16][5][H][W]
+    uint16_t *feat;      // [S][H][W][16][6]  k0..k4 + pad per (position, frac): one 12-byte load per candidate
+    uint16_t *feat0;     // [S][H][W][6]      plane-0 copy for the wide integer search
     uint32_t *sort_pos;  // [S][W*H]  (tx << 16) | ty, ordered by (sum, tx, ty)
     uint32_t *sort_k12;  // [S][W*H]  kar1 | kar2 << 16 of that position
     uint32_t *sort_k34;  // [S][W*H]  kar3 | kar4 << 16 of that position
@@ -370,6 +372,42 @@ __device__ __forceinline__ int mc_chroma(const uint8_t *__restrict__ R, int Wc, 
     return ((8 - xl) * (8 - yl) * R[y0 + x0] + xl * (8 - yl) * R[y0 + x1] + (8 - xl) * yl * R[y1 + x0] +
             xl * yl * R[y1 + x1] + 32) >>
            6;
+}
+
+// 4 / 8 consecutive bytes at an arbitrary byte address with aligned dword loads + v_alignbyte
+// (the arrays are allocated with 256 bytes of slack, so the trailing dword is always readable)
+__device__ __forceinline__ uint32_t load_u8x4(const uint8_t *__restrict__ p)
+{
+    const uint32_t *a = (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
+    uint32_t sh = (uint32_t)((uintptr_t)p & 3);
+    return __builtin_amdgcn_alignbyte(a[1], a[0], sh);
+}
+__device__ __forceinline__ void load_u8x8(const uint8_t *__restrict__ p, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t *a = (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
+    uint32_t sh = (uint32_t)((uintptr_t)p & 3);
+    uint32_t w0 = a[0], w1 = a[1], w2 = a[2];
+    lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+}
+
+// luma prediction of 4 consecutive samples (x..x+3, y) of the MB at (xP,yP): when every target
+// position lies inside the picture the motion-compensated value IS the interpolated plane
+// (identical clamped taps), read as packed bytes; otherwise the exact per-sample path.
+__device__ __forceinline__ void mc_luma4(const uint8_t *__restrict__ R, const uint8_t *__restrict__ Ps, size_t ysz,
+                                         int W, int H, int xP, int yP, int x, int y, int mvx, int mvy, int out[4])
+{
+    int X = xP + x + (mvx >> 2), Y = yP + y + (mvy >> 2);
+    if (X >= 0 && X + 3 < W && Y >= 0 && Y < H) {
+        uint32_t v = load_u8x4(Ps + (size_t)((mvy & 3) * 4 + (mvx & 3)) * ysz + (size_t)Y * W + X);
+        out[0] = v & 0xff;
+        out[1] = (v >> 8) & 0xff;
+        out[2] = (v >> 16) & 0xff;
+        out[3] = v >> 24;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[k] = mc_luma(R, W, H, xP, yP, x + k, y, mvx, mvy);
+    }
 }
 
 // ---------------------------------------------------------------- wave helpers

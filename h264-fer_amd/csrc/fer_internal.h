@@ -3,17 +3,19 @@
 #include "fer_dev.h"
 
 struct FerSortTmp {
-    uint16_t *keys_in, *keys_out;
+    uint32_t *keys_in, *keys_out;
     uint32_t *vals_in, *vals_out;
     void *tmp;
     size_t tmp_bytes;
+    unsigned *seg_begin;  // [S+1] segment offsets (stream s = [s*n, (s+1)*n))
 };
 
-size_t fer_sort_tmp_bytes(int n);
+size_t fer_sort_tmp_bytes(int n, int S);
 void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStream_t st);
 void fer_launch_frame_sad(const FerDev &d, hipStream_t st);
 void fer_launch_me_pre(const FerDev &d, hipStream_t st);
 void fer_launch_me_resolve(const FerDev &d, hipStream_t st);
+int fer_me_resolve_launches(const FerDev &d);
 void fer_launch_p_resid(const FerDev &d, hipStream_t st);
 void fer_launch_intra(const FerDev &d, hipStream_t st);
 void fer_launch_cavlc(const FerDev &d, hipStream_t st);

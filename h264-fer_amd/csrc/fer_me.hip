@@ -50,34 +50,52 @@ __device__ __forceinline__ void wl_insert(WList &L, int K, int lane, bool valid,
     }
 }
 
-// the 9-term feature distance of F/moestimation.cpp:267-276 at (frac, refy, refx)
-__device__ __forceinline__ int feat_dist(const uint16_t *__restrict__ Fs, size_t ysz, int W, int frac, int refy,
-                                         int refx, const int s[5])
+// the 9-term feature distance of F/moestimation.cpp:267-276 from one 12-byte feature record
+__device__ __forceinline__ int feat_dist_rec(const uint16_t *__restrict__ rec, const int s[5])
 {
-    const uint16_t *F = Fs + (size_t)frac * 5 * ysz + (size_t)refy * W + refx;
-    int k0 = F[0], k1 = F[ysz], k2 = F[2 * ysz], k3 = F[3 * ysz], k4 = F[4 * ysz];
+    const uint32_t *r = (const uint32_t *)rec;
+    uint32_t a = r[0], b = r[1], c = r[2];
+    int k0 = (int)(a & 0xffff), k1 = (int)(a >> 16), k2 = (int)(b & 0xffff), k3 = (int)(b >> 16), k4 = (int)(c & 0xffff);
     return iabs(s[0] - k0) + iabs(s[1] - k1) + iabs(s[0] - s[1] - k0 + k1) + iabs(s[2] - k2) +
            iabs(s[0] - s[2] - k0 + k2) + iabs(s[3] - k3) + iabs(s[0] - s[3] - k0 + k3) + iabs(s[4] - k4) +
            iabs(s[0] - s[4] - k0 + k4);
 }
+// ... at (frac, refy, refx) of the all-fracs array
+__device__ __forceinline__ int feat_dist(const uint16_t *__restrict__ Fs, size_t ysz, int W, int frac, int refy,
+                                         int refx, const int s[5])
+{
+    (void)ysz;
+    return feat_dist_rec(Fs + (((size_t)refy * W + refx) * 16 + frac) * 6, s);
+}
 
 // SAD of the 8x8 source block against interpolated plane (F/moestimation.cpp:175-195).
-// 8 lanes (rows) per candidate, 8 candidates per call: lane = cand*8 + row.  Returns the
-// full SAD in every lane of the group.
+// 8 lanes (rows) per candidate, 8 candidates per call: lane = cand*8 + row; src = the lane's
+// source row packed in two dwords.  Returns the full SAD in every lane of the group.
 __device__ __forceinline__ int sad8_rows(const uint8_t *__restrict__ Ps, size_t ysz, int W, int H, int xP, int yP,
-                                         int mvx, int mvy, int row, const int src[8])
+                                         int mvx, int mvy, int row, uint32_t s0, uint32_t s1)
 {
     int xPi = iclamp(xP + (mvx >> 2), 0, W - 1), yPi = iclamp(yP + (mvy >> 2), 0, H - 1);
     const uint8_t *R = Ps + (size_t)((mvx & 3) + (mvy & 3) * 4) * ysz + (size_t)min(yPi + row, H - 1) * W;
-    int s = 0;
+    uint32_t r0, r1;
+    if (xPi + 7 < W) {
+        load_u8x8(R + xPi, r0, r1);
+    } else {  // right edge: the reference clamps each column (F/moestimation.cpp:189)
+        r0 = r1 = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) s += iabs(src[j] - (int)R[min(xPi + j, W - 1)]);
+        for (int j = 0; j < 4; j++) {
+            r0 |= (uint32_t)R[min(xPi + j, W - 1)] << (8 * j);
+            r1 |= (uint32_t)R[min(xPi + 4 + j, W - 1)] << (8 * j);
+        }
+    }
+    int s = (int)__builtin_amdgcn_sad_u8(r1, s1, __builtin_amdgcn_sad_u8(r0, s0, 0));
     return oct_sum(s);
 }
 
 // ------------------------------------------------------------------ k_me_pre
+#define ME_WIDE_LDS 1156  // (2*16+2)^2: WindowSize <= 32 takes the LDS route (4.6 KB per wave)
 __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
 {
+    __shared__ int wide_m[ME_WIDE_LDS];
     const int lane = threadIdx.x;
     const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;
@@ -86,7 +104,7 @@ __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
     const size_t ysz = d.ysz;
     const uint8_t *Y = d.curY + (size_t)s * ysz;
     const uint8_t *Ps = d.interp + (size_t)s * 16 * ysz;
-    const uint16_t *Fs = d.feat + (size_t)s * 80 * ysz;
+    const uint16_t *Fs = d.feat + (size_t)s * 96 * ysz;
     const int sx = ((mb % d.mbw) << 4) + (part & 1) * 8, sy = ((mb / d.mbw) << 4) + (part >> 1) * 8;
     const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
 
@@ -101,27 +119,53 @@ __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
     su[4] = wave_sum((px & 3) > 1 ? 0 : v);
     if (lane < 5) d.suma[pidx * 5 + lane] = su[lane];
 
-    // source rows for the SAD groups
-    int row = lane & 7, src[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) src[j] = Y[(size_t)(sy + row) * W + sx + j];
+    // source rows for the SAD groups (sx is a multiple of 8: aligned dwords)
+    const int row = lane & 7;
+    const uint32_t src0 = *(const uint32_t *)(Y + (size_t)(sy + row) * W + sx);
+    const uint32_t src1 = *(const uint32_t *)(Y + (size_t)(sy + row) * W + sx + 4);
 
     // ---- stage 3: MEstimation(+-W/2, frac 0, centre 0) then MEstimation(+-W/16, 16 fracs, centre 0)
     WList L;
     L.m = INF_M;
     L.xy = 0;
     const int R = d.window / 2, n = 2 * R + 1;
-    for (int base = 0; base < n * n; base += 64) {
-        int c = base + lane;
-        int tx = c / n - R, ty = c % n - R;
-        int rx = sx + tx, ry = sy + ty;
-        bool ok = c < n * n && rx >= 0 && rx < W && ry >= 0 && ry < H;
-        int m = 0;
-        if (ok) m = (iabs(tx) + iabs(ty) + 4) * feat_dist(Fs, ysz, W, 0, ry, rx, su);
-        wl_insert(L, 33, lane, ok, m, pack_xy(tx * 4, ty * 4));
+    const uint16_t *F0 = d.feat0 + (size_t)s * 6 * ysz;
+    if (d.dbg & 1) {
+    } else if (n * n <= ME_WIDE_LDS) {
+        // pass A: lanes run along x (contiguous 12-byte records); metrics land in LDS at their
+        // arrival index (tx outer, ty inner).  pass B: ordered insertion from LDS.
+        for (int base = 0; base < n * n; base += 64) {
+            int c = base + lane;
+            if (c < n * n) {
+                int iy = c / n, ix = c % n;
+                int tx = ix - R, ty = iy - R;
+                int rx = sx + tx, ry = sy + ty;
+                int m = -1;
+                if (rx >= 0 && rx < W && ry >= 0 && ry < H)
+                    m = (iabs(tx) + iabs(ty) + 4) * feat_dist_rec(F0 + ((size_t)ry * W + rx) * 6, su);
+                wide_m[ix * n + iy] = m;
+            }
+        }
+        __syncthreads();
+        for (int base = 0; base < n * n; base += 64) {
+            int c = base + lane;
+            int m = c < n * n ? wide_m[c] : -1;
+            int tx = c / n - R, ty = c % n - R;
+            wl_insert(L, 33, lane, m >= 0, m, pack_xy(tx * 4, ty * 4));
+        }
+    } else {
+        for (int base = 0; base < n * n; base += 64) {
+            int c = base + lane;
+            int tx = c / n - R, ty = c % n - R;
+            int rx = sx + tx, ry = sy + ty;
+            bool ok = c < n * n && rx >= 0 && rx < W && ry >= 0 && ry < H;
+            int m = 0;
+            if (ok) m = (iabs(tx) + iabs(ty) + 4) * feat_dist_rec(F0 + ((size_t)ry * W + rx) * 6, su);
+            wl_insert(L, 33, lane, ok, m, pack_xy(tx * 4, ty * 4));
+        }
     }
     const int r2 = d.window / 16, n2w = 2 * r2 + 1;
-    for (int base = 0; base < n2w * n2w * 16; base += 64) {
+    for (int base = 0; base < n2w * n2w * 16 && !(d.dbg & 2); base += 64) {
         int c = base + lane;
         int frac = c & 15, pos = c >> 4;
         int tx = pos / n2w - r2, ty = pos % n2w - r2;
@@ -132,11 +176,11 @@ __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
         wl_insert(L, 33, lane, ok, m, pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2)));
     }
     int n3 = __popcll(__ballot(lane < 33 && L.m < 100000000));
-    for (int base = 0; base < n3; base += 8) {
+    for (int base = 0; base < n3 && !(d.dbg & 4); base += 8) {
         int j = base + (lane >> 3);
         int xy = __shfl(L.xy, j < 33 ? j : 0);
         int bx = unp_x(xy), by = unp_y(xy);
-        int sad = sad8_rows(Ps, ysz, W, H, sx, sy, bx, by, row, src);
+        int sad = sad8_rows(Ps, ysz, W, H, sx, sy, bx, by, row, src0, src1);
         if (j < n3 && row == 0) {
             int *o = d.st3 + (pidx * 33 + j) * 3;
             o[0] = bx;
@@ -152,12 +196,26 @@ __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
     const uint32_t *sk12 = d.sort_k12 + (size_t)s * ysz;
     const uint32_t *sk34 = d.sort_k34 + (size_t)s * ysz;
     int tren = 0;
-    if (!d.basic) {
+    if (!d.basic && !(d.dbg & 8)) {
         for (int j = 0; j <= 180; j++) {
             for (int side = 0; side < 2; side++) {
                 int a = side ? su[0] + j : su[0] - j;
                 if (a < 0 || a >= 16384) continue;
                 int k0 = kol[a], k1 = kol[a + 1];
+                // A bucket is ordered by (tx, ty) and the filter needs |tx - sx| < 280: probe 64
+                // evenly spaced entries once and walk only the slice whose tx can pass (the exact
+                // filter below still decides, so the candidate set and its order are unchanged).
+                if (k1 - k0 > 128) {
+                    int len = k1 - k0;
+                    int pk = k0 + (int)(((long long)len * lane) >> 6);
+                    int ptx = (int)(spos[pk] >> 16);
+                    int nlo = __popcll(__ballot(ptx <= sx - 280));  // probes certainly left of the window
+                    int nhi = __popcll(__ballot(ptx < sx + 280));   // probes not yet right of it
+                    int s0 = nlo > 0 ? k0 + (int)(((long long)len * (nlo - 1)) >> 6) : k0;
+                    int s1 = nhi < 64 ? k0 + (int)(((long long)len * nhi) >> 6) : k1;
+                    k0 = s0;
+                    k1 = s1;
+                }
                 for (int base = k0; base < k1; base += 64) {
                     int k = base + lane;
                     bool ok = false;
@@ -197,11 +255,12 @@ __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
 }
 
 // ------------------------------------------------------------------ MV prediction (a18)
+// Every macroblock of a P picture keeps one vector per 8x8 quadrant in d.mv (for 16x16, 16x8,
+// 8x16 and P_Skip the quadrants simply repeat the partition vector), so the neighbour partition
+// lookup of F/mode_pred.cpp:102-110 reduces to "quadrant that contains the neighbour sample".
 struct MvCtx {
-    const int *mb_type;  // stream base
-    const short *mv;     // stream base [nmb][4][2]
-    int mbw, cur, type;  // type = current mb_type
-    int cx[4], cy[4];    // quadrant MVs of the current MB as far as known
+    const short *mv;  // stream base [nmb][4][2]
+    int mbw, cur, type;
 };
 
 __device__ __forceinline__ int p_part_w(int t) { return (t == 0 || t == 1 || t == FER_P_SKIP) ? 16 : 8; }
@@ -243,15 +302,9 @@ __device__ void nbr_fetch(const MvCtx &c, int xN, int yN, bool &valid, int &mx, 
         }
     }
     if (!valid) return;
-    int t = (mbN == cur) ? c.type : c.mb_type[mbN];
-    int part = ((yW / p_part_h(t)) << 1) + (xW / p_part_w(t));
-    if (mbN == cur) {
-        mx = c.cx[part];
-        my = c.cy[part];
-    } else {
-        mx = c.mv[((size_t)mbN * 4 + part) * 2];
-        my = c.mv[((size_t)mbN * 4 + part) * 2 + 1];
-    }
+    int q = ((yW >> 3) << 1) + (xW >> 3);
+    mx = c.mv[((size_t)mbN * 4 + q) * 2];
+    my = c.mv[((size_t)mbN * 4 + q) * 2 + 1];
 }
 
 __device__ __forceinline__ int med3(int a, int b, int c) { return max(min(a, b), min(c, max(a, b))); }
@@ -340,17 +393,51 @@ __device__ void predict_luma(const MvCtx &c, int part, int &ox, int &oy)
     oy = med3(my[0], my[1], my[2]);
 }
 
+// SAD of up to K list entries, 8 per round, and the ordered first-minimum cost update
+// (F/moestimation.cpp:460-468): cost = SAD + |mv - mvp|, strict < in list order.
+__device__ __forceinline__ void eval_list(const WList &L, int K, int cnt, int lane, const uint8_t *__restrict__ Ps,
+                                          size_t ysz, int W, int H, int sx, int sy, uint32_t src0, uint32_t src1,
+                                          int mvpx, int mvpy, int &bmin, int &bx, int &by)
+{
+    const int row = lane & 7;
+    for (int base = 0; base < cnt; base += 8) {
+        int j = base + (lane >> 3);
+        int xy = __shfl(L.xy, j < K ? j : 0);
+        int cxv = unp_x(xy), cyv = unp_y(xy);
+        int sad = sad8_rows(Ps, ysz, W, H, sx, sy, cxv, cyv, row, src0, src1);
+        int cost = j < cnt ? sad + iabs(cxv - mvpx) + iabs(cyv - mvpy) : 2000000000;
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            int cg = lane_bcast(cost, g * 8), xg = lane_bcast(cxv, g * 8), yg = lane_bcast(cyv, g * 8);
+            if (cg < bmin) {
+                bmin = cg;
+                bx = xg;
+                by = yg;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ k_me_resolve
+// One wavefront per 8x8 partition, launched per anti-diagonal gx + 3*gy of the PARTITION grid:
+// a partition needs the final vectors of its left, up, up-right and up-left neighbours only, so
+// the serial chain is one partition long (half of what a macroblock-level wavefront would need)
+// and twice as many wavefronts are in flight per launch.  Partition 0 of a macroblock also makes
+// the P_Skip decision; partition 3 merges, derives mvd and does the final prediction + snapping.
+#define ST1_UNROLL 7
 __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
 {
     const int lane = threadIdx.x;
     const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;
-    // k-th macroblock on the anti-diagonal mbx + 2*mby == diag
-    int y_lo = diag - (d.mbw - 1);
-    y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
-    int mby = y_lo + blockIdx.x, mbx = diag - 2 * mby;
-    if (mby >= d.mbh || mbx < 0 || mbx >= d.mbw) return;
+    // wavefront index f = gx + 3*gy: besides left / up / up-right / up-left, the P_Skip prediction of
+    // partition 0 reads the lower-left quadrant of the up-right MACROBLOCK, i.e. partition (gx+2, gy-1)
+    const int gw = d.mbw * 2, gh = d.mbh * 2;
+    int y_lo = diag - (gw - 1);
+    y_lo = y_lo > 0 ? (y_lo + 2) / 3 : 0;
+    const int gy = y_lo + blockIdx.x, gx = diag - 3 * gy;
+    if (gy >= gh || gx < 0 || gx >= gw) return;
+    const int mbx = gx >> 1, mby = gy >> 1, part = (gy & 1) * 2 + (gx & 1);
     const int mb = mby * d.mbw + mbx;
     const int W = d.W, H = d.H, Wc = d.Wc, Hc = d.Hc;
     const size_t ysz = d.ysz, csz = d.csz;
@@ -359,172 +446,169 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
     const uint8_t *RY = d.refY + (size_t)s * ysz;
     const uint8_t *RCb = d.refCb + (size_t)s * csz, *RCr = d.refCr + (size_t)s * csz;
     const uint8_t *Ps = d.interp + (size_t)s * 16 * ysz;
-    const uint16_t *Fs = d.feat + (size_t)s * 80 * ysz;
+    const uint16_t *Fs = d.feat + (size_t)s * 96 * ysz;
     int *mbt = d.mb_type + (size_t)s * d.nmb;
     short *mvs = d.mv + (size_t)s * d.nmb * 8;
     const int xp = mbx << 4, yp = mby << 4;
 
     MvCtx c;
-    c.mb_type = mbt;
     c.mv = mvs;
     c.mbw = d.mbw;
     c.cur = mb;
     c.type = FER_P_SKIP;
-    for (int i = 0; i < 4; i++) c.cx[i] = c.cy[i] = 0;
 
-    // ---- P_Skip candidate, F/mode_pred.cpp:381-402 + F/moestimation.cpp:402-425
-    int smx = 0, smy = 0;
-    if (!(mb < d.mbw || mbx == 0)) {
-        int up = mb - d.mbw, lf = mb - 1;
-        bool zu = (mvs[(up * 4 + 2) * 2] | mvs[(up * 4 + 2) * 2 + 1]) == 0;
-        bool zl = (mvs[(lf * 4 + 1) * 2] | mvs[(lf * 4 + 1) * 2 + 1]) == 0;
-        if (!(zu || zl)) predict_luma(c, 0, smx, smy);
-    }
-    // each lane owns 4 luma samples: x = (lane&3)*4.., y = lane>>2 .. wait 16 rows: lane>>2 in 0..15
+    // each lane owns 4 luma samples (lx..lx+3, ly) and one sample of each chroma plane
     const int lx = (lane & 3) * 4, ly = lane >> 2;
-    int srcv[4], pred[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        srcv[k] = Y[(size_t)(yp + ly) * W + xp + lx + k];
-        pred[k] = mc_luma(RY, W, H, xp, yp, lx + k, ly, smx, smy);
-    }
-    int MAXDIFF = d.maxdiff_set;
-    if (d.maxdiff_set == -1) {  // adaptive tolerance, F/moestimation.cpp:407-419
-        int mean = wave_sum(srcv[0] + srcv[1] + srcv[2] + srcv[3]) / 256;
-        int dev = wave_sum(iabs(srcv[0] - mean) + iabs(srcv[1] - mean) + iabs(srcv[2] - mean) + iabs(srcv[3] - mean));
-        MAXDIFF = dev / 256;
-        if (MAXDIFF < 3) MAXDIFF = 3;
-    }
-    bool exact = true;
-#pragma unroll
-    for (int k = 0; k < 4; k++) exact = exact && iabs(srcv[k] - pred[k]) <= MAXDIFF;
-    // chroma sample owned by the lane: (lane&7, lane>>3) of both planes
     const int cxl = lane & 7, cyl = lane >> 3;
-    if (__all(exact)) {
-        // P_Skip: reconstruction == prediction (F/inttransform.cpp:215-231)
+
+    if (part == 0) {
+        // ---- P_Skip candidate, F/mode_pred.cpp:381-402 + F/moestimation.cpp:402-425
+        int smx = 0, smy = 0;
+        if (!(mb < d.mbw || mbx == 0)) {
+            int up = mb - d.mbw, lf = mb - 1;
+            bool zu = (mvs[(up * 4 + 2) * 2] | mvs[(up * 4 + 2) * 2 + 1]) == 0;
+            bool zl = (mvs[(lf * 4 + 1) * 2] | mvs[(lf * 4 + 1) * 2 + 1]) == 0;
+            if (!(zu || zl)) predict_luma(c, 0, smx, smy);
+        }
+        int srcv[4], pred[4];
+        uint32_t sv = *(const uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx);
 #pragma unroll
-        for (int k = 0; k < 4; k++) Y[(size_t)(yp + ly) * W + xp + lx + k] = (uint8_t)pred[k];
-        Cb[(size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl] = (uint8_t)mc_chroma(RCb, Wc, Hc, xp / 2, yp / 2, cxl, cyl, smx, smy);
-        Cr[(size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl] = (uint8_t)mc_chroma(RCr, Wc, Hc, xp / 2, yp / 2, cxl, cyl, smx, smy);
-        if (lane < 4) {
-            mvs[(mb * 4 + lane) * 2] = (short)smx;
-            mvs[(mb * 4 + lane) * 2 + 1] = (short)smy;
+        for (int k = 0; k < 4; k++) srcv[k] = (sv >> (8 * k)) & 0xff;
+        mc_luma4(RY, Ps, ysz, W, H, xp, yp, lx, ly, smx, smy, pred);
+        int MAXDIFF = d.maxdiff_set;
+        if (d.maxdiff_set == -1) {  // adaptive tolerance, F/moestimation.cpp:407-419
+            int mean = wave_sum(srcv[0] + srcv[1] + srcv[2] + srcv[3]) / 256;
+            int dev = wave_sum(iabs(srcv[0] - mean) + iabs(srcv[1] - mean) + iabs(srcv[2] - mean) + iabs(srcv[3] - mean));
+            MAXDIFF = dev / 256;
+            if (MAXDIFF < 3) MAXDIFF = 3;
         }
-        if (lane == 0) {
-            mbt[mb] = FER_P_SKIP;
-            atomicAdd(&d.stats[s * 5 + 0], 1);
+        bool exact = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) exact = exact && iabs(srcv[k] - pred[k]) <= MAXDIFF;
+        if (__all(exact)) {
+            // P_Skip: reconstruction == prediction (F/inttransform.cpp:215-231)
+            *(uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx) =
+                (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
+            Cb[(size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl] = (uint8_t)mc_chroma(RCb, Wc, Hc, xp / 2, yp / 2, cxl, cyl, smx, smy);
+            Cr[(size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl] = (uint8_t)mc_chroma(RCr, Wc, Hc, xp / 2, yp / 2, cxl, cyl, smx, smy);
+            if (lane < 4) {
+                mvs[(mb * 4 + lane) * 2] = (short)smx;
+                mvs[(mb * 4 + lane) * 2 + 1] = (short)smy;
+            }
+            if (lane == 0) {
+                mbt[mb] = FER_P_SKIP;
+                atomicAdd(&d.stats[s * 5 + 0], 1);
+            }
+            return;
         }
+        if (lane == 0) mbt[mb] = FER_P_8x8ref0;  // also clears a P_Skip left by the previous picture
+    } else if (mbt[mb] == FER_P_SKIP) {
         return;
     }
 
-    // ---- four 8x8 partitions as P_8x8ref0
+    // ---- search of this 8x8 partition as part of a P_8x8ref0 macroblock
     c.type = FER_P_8x8ref0;
-    int mvx[4], mvy[4];
+    int mvpx, mvpy;
+    predict_luma(c, part, mvpx, mvpy);
+    const int genx = mvpx >> 2, geny = mvpy >> 2;
+    const int sx = xp + (part & 1) * 8, sy = yp + (part >> 1) * 8;
+    const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
+    int su[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) su[k] = d.suma[pidx * 5 + k];
     const int row = lane & 7;
-    for (int i = 0; i < 4; i++) {
-        int mvpx, mvpy;
-        predict_luma(c, i, mvpx, mvpy);
-        const int genx = mvpx >> 2, geny = mvpy >> 2;
-        const int sx = xp + (i & 1) * 8, sy = yp + (i >> 1) * 8;
-        const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + i;
-        int su[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) su[k] = d.suma[pidx * 5 + k];
-        int src[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) src[j] = Y[(size_t)(sy + row) * W + sx + j];
-        int bx = 0, by = 0, bmin = 2000000000;
+    const uint32_t src0 = *(const uint32_t *)(Y + (size_t)(sy + row) * W + sx);
+    const uint32_t src1 = *(const uint32_t *)(Y + (size_t)(sy + row) * W + sx + 4);
+    int bx = 0, by = 0, bmin = 2000000000;
 
-        // stage 1: +-W/16 around the predictor, all 16 fractional planes (K = 17)
-        WList L;
-        L.m = INF_M;
-        L.xy = 0;
-        const int r1 = d.window / 16, n1 = 2 * r1 + 1;
-        for (int base = 0; base < n1 * n1 * 16; base += 64) {
-            int cc = base + lane;
+    // stage 1: +-W/16 around the predictor, all 16 fractional planes (K = 17).  The feature
+    // records of ST1_UNROLL batches are fetched before the ordered insertion starts.
+    WList L;
+    L.m = INF_M;
+    L.xy = 0;
+    const int r1 = d.window / 16, n1 = 2 * r1 + 1, tot1 = (d.dbg & 16) ? 0 : n1 * n1 * 16;
+    for (int base0 = 0; base0 < tot1; base0 += 64 * ST1_UNROLL) {
+        int m[ST1_UNROLL], xy[ST1_UNROLL];
+        bool ok[ST1_UNROLL];
+#pragma unroll
+        for (int u = 0; u < ST1_UNROLL; u++) {
+            int cc = base0 + u * 64 + lane;
             int frac = cc & 15, pos = cc >> 4;
             int tx = genx - r1 + pos / n1, ty = geny - r1 + pos % n1;
             int rx = sx + tx, ry = sy + ty;
-            bool ok = cc < n1 * n1 * 16 && rx >= 0 && rx < W && ry >= 0 && ry < H;
-            int m = 0;
-            if (ok) m = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, su);
-            wl_insert(L, 17, lane, ok, m, pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2)));
+            ok[u] = cc < tot1 && rx >= 0 && rx < W && ry >= 0 && ry < H;
+            m[u] = 0;
+            if (ok[u]) m[u] = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, su);
+            xy[u] = pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2));
         }
-        int cnt = __popcll(__ballot(lane < 17 && L.m < 100000000));
-        for (int base = 0; base < cnt; base += 8) {
-            int j = base + (lane >> 3);
-            int xy = __shfl(L.xy, j < 17 ? j : 0);
-            int cxv = unp_x(xy), cyv = unp_y(xy);
-            int sad = sad8_rows(Ps, ysz, W, H, sx, sy, cxv, cyv, row, src);
-            int cost = j < cnt ? sad + iabs(cxv - mvpx) + iabs(cyv - mvpy) : 2000000000;
-            // ordered first-minimum over the 8 candidates of this round
-            for (int g = 0; g < 8; g++) {
-                int cg = lane_bcast(cost, g * 8), xg = lane_bcast(cxv, g * 8), yg = lane_bcast(cyv, g * 8);
-                if (cg < bmin) {
-                    bmin = cg;
-                    bx = xg;
-                    by = yg;
-                }
-            }
-        }
-        if (!d.basic) {
-            // stage 2: re-rank the precomputed candidate set with the predictor weight (K = 33)
-            L.m = INF_M;
-            int n2 = min(d.st2n[pidx], FER_ST2_CAP);
-            const int *c2 = d.st2 + pidx * FER_ST2_CAP * 2;
-            for (int base = 0; base < n2; base += 64) {
-                int cc = base + lane;
-                bool ok = cc < n2;
-                int m = 0, xy = 0;
-                if (ok) {
-                    int pxy = c2[cc * 2], D = c2[cc * 2 + 1];
-                    int tx = unp_x(pxy), ty = unp_y(pxy);
-                    m = (iabs(tx - genx) + iabs(ty - geny) + 4) * D;
-                    xy = pack_xy(tx * 4, ty * 4);
-                }
-                wl_insert(L, 33, lane, ok, m, xy);
-            }
-            cnt = __popcll(__ballot(lane < 33 && L.m < 100000000));
-            for (int base = 0; base < cnt; base += 8) {
-                int j = base + (lane >> 3);
-                int xy = __shfl(L.xy, j < 33 ? j : 0);
-                int cxv = unp_x(xy), cyv = unp_y(xy);
-                int sad = sad8_rows(Ps, ysz, W, H, sx, sy, cxv, cyv, row, src);
-                int cost = j < cnt ? sad + iabs(cxv - mvpx) + iabs(cyv - mvpy) : 2000000000;
-                for (int g = 0; g < 8; g++) {
-                    int cg = lane_bcast(cost, g * 8), xg = lane_bcast(cxv, g * 8), yg = lane_bcast(cyv, g * 8);
-                    if (cg < bmin) {
-                        bmin = cg;
-                        bx = xg;
-                        by = yg;
-                    }
-                }
-            }
-            // stage 3: precomputed survivors of the centre-0 searches
-            int n3 = d.st3n[pidx];
-            const int *c3 = d.st3 + pidx * 33 * 3;
-            int cost = 2000000000, cxv = 0, cyv = 0;
-            if (lane < n3) {
-                cxv = c3[lane * 3];
-                cyv = c3[lane * 3 + 1];
-                cost = c3[lane * 3 + 2] + iabs(cxv - mvpx) + iabs(cyv - mvpy);
-            }
-            for (int g = 0; g < n3; g++) {
-                int cg = lane_bcast(cost, g), xg = lane_bcast(cxv, g), yg = lane_bcast(cyv, g);
-                if (cg < bmin) {
-                    bmin = cg;
-                    bx = xg;
-                    by = yg;
-                }
-            }
-        }
-        mvx[i] = bx;
-        mvy[i] = by;
-        c.cx[i] = bx;
-        c.cy[i] = by;
+#pragma unroll
+        for (int u = 0; u < ST1_UNROLL; u++)
+            if (base0 + u * 64 < tot1) wl_insert(L, 17, lane, ok[u], m[u], xy[u]);
     }
+    int cnt = __popcll(__ballot(lane < 17 && L.m < 100000000));
+    eval_list(L, 17, cnt, lane, Ps, ysz, W, H, sx, sy, src0, src1, mvpx, mvpy, bmin, bx, by);
 
-    // ---- partition merge, F/moestimation.cpp:529-551
+    if (!d.basic && !(d.dbg & 32)) {
+        // stage 2: re-rank the precomputed candidate set with the predictor weight (K = 33)
+        L.m = INF_M;
+        int n2 = min(d.st2n[pidx], FER_ST2_CAP);
+        const int2 *c2 = (const int2 *)(d.st2 + pidx * FER_ST2_CAP * 2);
+        for (int base0 = 0; base0 < n2; base0 += 64 * 3) {
+            int m[3], xy[3];
+            bool ok[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                int cc = base0 + u * 64 + lane;
+                ok[u] = cc < n2;
+                m[u] = 0;
+                xy[u] = 0;
+                if (ok[u]) {
+                    int2 e = c2[cc];
+                    int tx = unp_x(e.x), ty = unp_y(e.x);
+                    m[u] = (iabs(tx - genx) + iabs(ty - geny) + 4) * e.y;
+                    xy[u] = pack_xy(tx * 4, ty * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; u++)
+                if (base0 + u * 64 < n2) wl_insert(L, 33, lane, ok[u], m[u], xy[u]);
+        }
+        cnt = __popcll(__ballot(lane < 33 && L.m < 100000000));
+        eval_list(L, 33, cnt, lane, Ps, ysz, W, H, sx, sy, src0, src1, mvpx, mvpy, bmin, bx, by);
+        // stage 3: precomputed survivors of the centre-0 searches
+        int n3 = (d.dbg & 64) ? 0 : d.st3n[pidx];
+        const int *c3 = d.st3 + pidx * 33 * 3;
+        int cost = 2000000000, cxv = 0, cyv = 0;
+        if (lane < n3) {
+            cxv = c3[lane * 3];
+            cyv = c3[lane * 3 + 1];
+            cost = c3[lane * 3 + 2] + iabs(cxv - mvpx) + iabs(cyv - mvpy);
+        }
+        for (int g = 0; g < n3; g++) {
+            int cg = lane_bcast(cost, g), xg = lane_bcast(cxv, g), yg = lane_bcast(cyv, g);
+            if (cg < bmin) {
+                bmin = cg;
+                bx = xg;
+                by = yg;
+            }
+        }
+    }
+    if (lane == 0) {
+        mvs[(mb * 4 + part) * 2] = (short)bx;
+        mvs[(mb * 4 + part) * 2 + 1] = (short)by;
+    }
+    if (part != 3) return;
+
+    // ---- last partition: merge, mvd, final prediction, snapping (F/moestimation.cpp:529-584)
+    int mvx[4], mvy[4];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        mvx[i] = mvs[(mb * 4 + i) * 2];
+        mvy[i] = mvs[(mb * 4 + i) * 2 + 1];
+    }
+    mvx[3] = bx;
+    mvy[3] = by;
+    __threadfence_block();
     int type = FER_P_8x8ref0, stat = 4;
     if (mvx[0] == mvx[1] && mvx[0] == mvx[2] && mvx[0] == mvx[3] && mvy[0] == mvy[1] && mvy[0] == mvy[2] &&
         mvy[0] == mvy[3]) {
@@ -537,21 +621,19 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
         type = FER_P_8x16;
         stat = 3;
     }
-    // mvd under the final type, F/moestimation.cpp:552-564
+    // mvd under the final type.  Own earlier partitions are read from d.mv: quadrant 3 was just
+    // stored by lane 0; no prediction of partition <= 3 ever reads quadrant 3 of its own MB.
     c.type = type;
     int np = type == FER_P_L0_16x16 ? 1 : (type == FER_P_8x8ref0 ? 4 : 2);
     int dvx[4] = {0, 0, 0, 0}, dvy[4] = {0, 0, 0, 0};
     for (int i = 0; i < np; i++) {
-        int q = i;  // quadrant that carries partition i's vector
-        if (type == FER_P_16x8 && i == 1) q = 2;
+        int q = (type == FER_P_16x8 && i == 1) ? 2 : i;  // quadrant that carries partition i's vector
         int px_, py_;
         predict_luma(c, i, px_, py_);
         dvx[i] = mvx[q] - px_;
         dvy[i] = mvy[q] - py_;
     }
     if (lane < 4) {
-        mvs[(mb * 4 + lane) * 2] = (short)mvx[lane];
-        mvs[(mb * 4 + lane) * 2 + 1] = (short)mvy[lane];
         short *o = d.mvd + ((size_t)s * d.nmb + mb) * 8;
         o[lane * 2] = (short)dvx[lane];
         o[lane * 2 + 1] = (short)dvy[lane];
@@ -560,15 +642,25 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
         mbt[mb] = type;
         atomicAdd(&d.stats[s * 5 + stat], 1);
     }
-
-    // ---- final prediction and source snapping, F/moestimation.cpp:565-584
     {
-        int q = (ly >> 3) * 2 + (lx >> 3);
+        int srcv[4];
+        uint32_t sv = *(const uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int p = mc_luma(RY, W, H, xp, yp, lx + k, ly, mvx[q], mvy[q]);
-            if (iabs(srcv[k] - p) < MAXDIFF) Y[(size_t)(yp + ly) * W + xp + lx + k] = (uint8_t)p;
+        for (int k = 0; k < 4; k++) srcv[k] = (sv >> (8 * k)) & 0xff;
+        int MAXDIFF = d.maxdiff_set;
+        if (d.maxdiff_set == -1) {
+            int mean = wave_sum(srcv[0] + srcv[1] + srcv[2] + srcv[3]) / 256;
+            int dev = wave_sum(iabs(srcv[0] - mean) + iabs(srcv[1] - mean) + iabs(srcv[2] - mean) + iabs(srcv[3] - mean));
+            MAXDIFF = dev / 256;
+            if (MAXDIFF < 3) MAXDIFF = 3;
         }
+        int q = (ly >> 3) * 2 + (lx >> 3);
+        int pf[4];
+        mc_luma4(RY, Ps, ysz, W, H, xp, yp, lx, ly, mvx[q], mvy[q], pf);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) packed |= (uint32_t)(iabs(srcv[k] - pf[k]) < MAXDIFF ? pf[k] : srcv[k]) << (8 * k);
+        *(uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx) = packed;
         int qc = (cyl >> 2) * 2 + (cxl >> 2);
         size_t co = (size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl;
         int pb = mc_chroma(RCb, Wc, Hc, xp / 2, yp / 2, cxl, cyl, mvx[qc], mvy[qc]);
@@ -583,9 +675,12 @@ void fer_launch_me_pre(const FerDev &d, hipStream_t st)
     hipLaunchKernelGGL(k_me_pre, dim3(d.nmb * 4, d.S), dim3(64), 0, st, d);
 }
 
+int fer_me_resolve_launches(const FerDev &d) { return 2 * d.mbw + 3 * (2 * d.mbh - 1); }
+
 void fer_launch_me_resolve(const FerDev &d, hipStream_t st)
 {
-    int ndiag = d.mbw + 2 * (d.mbh - 1);
-    int maxk = min(d.mbh, (d.mbw + 1) / 2);
+    int gw = 2 * d.mbw, gh = 2 * d.mbh;
+    int ndiag = gw + 3 * (gh - 1);
+    int maxk = min(gh, (gw + 2) / 3);
     for (int dg = 0; dg < ndiag; dg++) hipLaunchKernelGGL(k_me_resolve, dim3(maxk, d.S), dim3(64), 0, st, d, dg);
 }

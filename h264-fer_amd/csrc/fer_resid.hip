@@ -29,8 +29,10 @@ __global__ __launch_bounds__(64) void k_p_resid(FerDev d)
         int lx = (lane & 3) * 4, ly = lane >> 2;
         int q = (ly >> 3) * 2 + (lx >> 3);
         int mx = mv[q * 2], my = mv[q * 2 + 1];
+        int pf[4];
+        mc_luma4(RY, d.interp + (size_t)s * 16 * d.ysz, d.ysz, W, H, xp, yp, lx, ly, mx, my, pf);
 #pragma unroll
-        for (int k = 0; k < 4; k++) pL[ly][lx + k] = (uint8_t)mc_luma(RY, W, H, xp, yp, lx + k, ly, mx, my);
+        for (int k = 0; k < 4; k++) pL[ly][lx + k] = (uint8_t)pf[k];
         int cx = lane & 7, cy = lane >> 3;
         int qc = (cy >> 2) * 2 + (cx >> 2);
         mx = mv[qc * 2];

@@ -174,7 +174,7 @@ class FerHip:
         which = BUF[name]
         n = self.nmb * self.S
         px = self.W * self.H * self.S
-        count = {1: px * 16, 2: px * 80, 3: px, 4: 16385 * self.S, 5: n, 6: n * 8, 7: n * 8, 8: n * 400, 9: n * 2,
+        count = {1: px * 16, 2: px * 96, 3: px, 4: 16385 * self.S, 5: n, 6: n * 8, 7: n * 8, 8: n * 400, 9: n * 2,
                  10: n * 24, 11: n * 16, 12: self.fsz * self.S, 13: self.fsz * self.S}[which]
         out = np.empty(count, _BUF_DTYPE[which])
         got = self.lib.ferhip_read_buffer(self.ctx, which, out.ctypes.data, out.nbytes)

@@ -118,7 +118,7 @@ int ferhip_fill_interpolated(ferhip_ctx *c);
 int ferhip_inter_encoding(ferhip_ctx *c);
 /* debug/test read-back of device state; which: see FERHIP_BUF_*; returns bytes copied */
 #define FERHIP_BUF_INTERP 1   /* uint8  [S][16][H][W] */
-#define FERHIP_BUF_FEAT 2     /* uint16 [S][16][5][H][W] */
+#define FERHIP_BUF_FEAT 2     /* uint16 [S][H][W][16][6] (k0..k4, pad) */
 #define FERHIP_BUF_SORTPOS 3  /* uint32 [S][W*H] */
 #define FERHIP_BUF_KOLIKO 4   /* int32  [S][16385] */
 #define FERHIP_BUF_MBTYPE 5   /* int32  [S][nmb] */

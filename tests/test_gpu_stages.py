@@ -41,10 +41,10 @@ def test_refprep_matches_oracle(pkg, fo):
     gi = g.read("INTERP").reshape(16, H, W)
     for f in range(16):
         assert np.array_equal(gi[f], o.interp(f)), f"interp plane {f}"
-    gf = g.read("FEAT").reshape(16, 5, H, W)
+    gf = g.read("FEAT").reshape(H, W, 16, 6)
     for f in range(16):
         for k in range(5):
-            assert np.array_equal(gf[f, k].astype(np.int32), o.kar(k, f)), (f, k)
+            assert np.array_equal(gf[:, :, f, k].astype(np.int32), o.kar(k, f)), (f, k)
     assert np.array_equal(g.read("KOLIKO")[:16384], o.koliko()[:16384])
     sp = g.read("SORTPOS")
     assert np.array_equal((sp >> 16).astype(np.int32), o.sorted(2))
