@@ -443,6 +443,24 @@ __device__ __forceinline__ int wave_sum(int v)
     return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
            __builtin_amdgcn_readlane(v, 48);
 }
+__device__ __forceinline__ int wave_min(int v)
+{
+    v = min(v, FER_DPP(v, DPP_QUAD_XOR1));
+    v = min(v, FER_DPP(v, DPP_QUAD_XOR2));
+    v = min(v, FER_DPP(v, DPP_ROW_HALF_MIRROR));
+    v = min(v, FER_DPP(v, DPP_ROW_MIRROR));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+    v = max(v, FER_DPP(v, DPP_QUAD_XOR1));
+    v = max(v, FER_DPP(v, DPP_QUAD_XOR2));
+    v = max(v, FER_DPP(v, DPP_ROW_HALF_MIRROR));
+    v = max(v, FER_DPP(v, DPP_ROW_MIRROR));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
 // value of lane `src` (wave-uniform index) in every lane
 __device__ __forceinline__ int lane_bcast(int v, int src)
 {

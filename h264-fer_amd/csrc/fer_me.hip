@@ -50,6 +50,84 @@ __device__ __forceinline__ void wl_insert(WList &L, int K, int lane, bool valid,
     }
 }
 
+// ---- top-K of a candidate set by (metric, arrival order), without serial insertion ----
+// The reference's list (F/moestimation.cpp:277-291) ends up holding the K smallest candidates
+// ordered by metric, ties by arrival.  With candidate (u, lane) arriving at index u*64 + lane
+// that is a selection problem: binary-search the K-th smallest metric with ballot counts, take
+// everything below it plus the earliest arrivals equal to it, then rank the <= K winners.
+// v[u] < 0 marks an invalid candidate.  sel = 4*64 ints of LDS scratch owned by the wavefront.
+template <int NB>
+__device__ void select_topk(const int (&v)[NB], const int (&xy)[NB], int K, int lane, int *sel, WList &L)
+{
+    int *key = sel, *kxy = sel + 64, *key2 = sel + 128, *kxy2 = sel + 192;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int total = 0, lmin = 0x7fffffff, lmax = -1;
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+        bool ok = v[u] >= 0;
+        total += __popcll(__ballot(ok));
+        if (ok) lmin = min(lmin, v[u]);
+        lmax = max(lmax, v[u]);
+    }
+    const int need = min(K, total);
+    L.m = INF_M;
+    L.xy = 0;
+    if (need == 0) return;
+    int lo = wave_min(lmin), hi;
+    if (__popcll(__ballot(lmin != 0x7fffffff)) >= need)
+        hi = wave_max(lmin != 0x7fffffff ? lmin : -1);  // >= need candidates are <= the largest lane minimum
+    else
+        hi = wave_max(lmax);
+    while (lo < hi) {  // smallest T with count(v <= T) >= need
+        int mid = lo + ((hi - lo) >> 1);
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < NB; u++) cnt += __popcll(__ballot(v[u] >= 0 && v[u] <= mid));
+        if (cnt >= need)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    const int T = lo;
+    int c_less = 0;
+#pragma unroll
+    for (int u = 0; u < NB; u++) c_less += __popcll(__ballot(v[u] >= 0 && v[u] < T));
+    const int take_eq = need - c_less;
+    int nsel = 0, eq_seen = 0;
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+        bool ok = v[u] >= 0;
+        bool eq = ok && v[u] == T;
+        unsigned long long meq = __ballot(eq);
+        bool take = (ok && v[u] < T) || (eq && eq_seen + __popcll(meq & lt) < take_eq);
+        unsigned long long mt = __ballot(take);
+        if (take) {
+            int pos = nsel + __popcll(mt & lt);
+            key[pos] = v[u];
+            kxy[pos] = xy[u];
+        }
+        nsel += __popcll(mt);
+        eq_seen += __popcll(meq);
+    }
+    __syncthreads();
+    int mk = lane < need ? key[lane] : INF_M, mxy = lane < need ? kxy[lane] : 0;
+    int rank = 0;
+    for (int i = 0; i < need; i++) {
+        int ki = key[i];
+        rank += (ki < mk) || (ki == mk && i < lane);
+    }
+    if (lane < need) {
+        key2[rank] = mk;
+        kxy2[rank] = mxy;
+    }
+    __syncthreads();
+    if (lane < need) {
+        L.m = key2[lane];
+        L.xy = kxy2[lane];
+    }
+    __syncthreads();
+}
+
 // the 9-term feature distance of F/moestimation.cpp:267-276 from one 12-byte feature record
 __device__ __forceinline__ int feat_dist_rec(const uint16_t *__restrict__ rec, const int s[5])
 {
@@ -93,9 +171,11 @@ __device__ __forceinline__ int sad8_rows(const uint8_t *__restrict__ Ps, size_t 
 
 // ------------------------------------------------------------------ k_me_pre
 #define ME_WIDE_LDS 1156  // (2*16+2)^2: WindowSize <= 32 takes the LDS route (4.6 KB per wave)
+#define ME_SEL_NB 25      // 64-candidate batches of stage 3 at WindowSize 32: 18 wide + 7 local
 __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
 {
     __shared__ int wide_m[ME_WIDE_LDS];
+    __shared__ int sel_lds[256];
     const int lane = threadIdx.x;
     const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;
@@ -129,11 +209,12 @@ __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
     L.m = INF_M;
     L.xy = 0;
     const int R = d.window / 2, n = 2 * R + 1;
+    const int r2 = d.window / 16, n2w = 2 * r2 + 1, nloc = n2w * n2w * 16;
     const uint16_t *F0 = d.feat0 + (size_t)s * 6 * ysz;
-    if (d.dbg & 1) {
-    } else if (n * n <= ME_WIDE_LDS) {
+    const int wb = (n * n + 63) >> 6;  // batches of the wide search
+    if (n * n <= ME_WIDE_LDS && wb + ((nloc + 63) >> 6) <= ME_SEL_NB && !(d.dbg & 3)) {
         // pass A: lanes run along x (contiguous 12-byte records); metrics land in LDS at their
-        // arrival index (tx outer, ty inner).  pass B: ordered insertion from LDS.
+        // arrival index (tx outer, ty inner).
         for (int base = 0; base < n * n; base += 64) {
             int c = base + lane;
             if (c < n * n) {
@@ -147,14 +228,31 @@ __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
             }
         }
         __syncthreads();
-        for (int base = 0; base < n * n; base += 64) {
-            int c = base + lane;
-            int m = c < n * n ? wide_m[c] : -1;
-            int tx = c / n - R, ty = c % n - R;
-            wl_insert(L, 33, lane, m >= 0, m, pack_xy(tx * 4, ty * 4));
+        int v[ME_SEL_NB], xy[ME_SEL_NB];
+#pragma unroll
+        for (int u = 0; u < ME_SEL_NB; u++) {
+            v[u] = -1;
+            xy[u] = 0;
+            if (u < wb) {
+                int c = u * 64 + lane;
+                if (c < n * n) {
+                    v[u] = wide_m[c];
+                    xy[u] = pack_xy((c / n - R) * 4, (c % n - R) * 4);
+                }
+            } else {
+                int c = (u - wb) * 64 + lane;
+                int frac = c & 15, pos = c >> 4;
+                int tx = pos / n2w - r2, ty = pos % n2w - r2;
+                int rx = sx + tx, ry = sy + ty;
+                if (c < nloc && rx >= 0 && rx < W && ry >= 0 && ry < H) {
+                    v[u] = (iabs(tx) + iabs(ty) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, su);
+                    xy[u] = pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2));
+                }
+            }
         }
+        select_topk<ME_SEL_NB>(v, xy, 33, lane, sel_lds, L);
     } else {
-        for (int base = 0; base < n * n; base += 64) {
+        for (int base = 0; base < n * n && !(d.dbg & 1); base += 64) {
             int c = base + lane;
             int tx = c / n - R, ty = c % n - R;
             int rx = sx + tx, ry = sy + ty;
@@ -163,17 +261,16 @@ __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
             if (ok) m = (iabs(tx) + iabs(ty) + 4) * feat_dist_rec(F0 + ((size_t)ry * W + rx) * 6, su);
             wl_insert(L, 33, lane, ok, m, pack_xy(tx * 4, ty * 4));
         }
-    }
-    const int r2 = d.window / 16, n2w = 2 * r2 + 1;
-    for (int base = 0; base < n2w * n2w * 16 && !(d.dbg & 2); base += 64) {
-        int c = base + lane;
-        int frac = c & 15, pos = c >> 4;
-        int tx = pos / n2w - r2, ty = pos % n2w - r2;
-        int rx = sx + tx, ry = sy + ty;
-        bool ok = c < n2w * n2w * 16 && rx >= 0 && rx < W && ry >= 0 && ry < H;
-        int m = 0;
-        if (ok) m = (iabs(tx) + iabs(ty) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, su);
-        wl_insert(L, 33, lane, ok, m, pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2)));
+        for (int base = 0; base < nloc && !(d.dbg & 2); base += 64) {
+            int c = base + lane;
+            int frac = c & 15, pos = c >> 4;
+            int tx = pos / n2w - r2, ty = pos % n2w - r2;
+            int rx = sx + tx, ry = sy + ty;
+            bool ok = c < nloc && rx >= 0 && rx < W && ry >= 0 && ry < H;
+            int m = 0;
+            if (ok) m = (iabs(tx) + iabs(ty) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, su);
+            wl_insert(L, 33, lane, ok, m, pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2)));
+        }
     }
     int n3 = __popcll(__ballot(lane < 33 && L.m < 100000000));
     for (int base = 0; base < n3 && !(d.dbg & 4); base += 8) {
@@ -427,6 +524,7 @@ __device__ __forceinline__ void eval_list(const WList &L, int K, int cnt, int la
 #define ST1_UNROLL 7
 __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
 {
+    __shared__ int sel_lds[256];
     const int lane = threadIdx.x;
     const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;
@@ -527,51 +625,54 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
     L.m = INF_M;
     L.xy = 0;
     const int r1 = d.window / 16, n1 = 2 * r1 + 1, tot1 = (d.dbg & 16) ? 0 : n1 * n1 * 16;
-    for (int base0 = 0; base0 < tot1; base0 += 64 * ST1_UNROLL) {
+    if (tot1 <= 64 * ST1_UNROLL) {
         int m[ST1_UNROLL], xy[ST1_UNROLL];
-        bool ok[ST1_UNROLL];
 #pragma unroll
         for (int u = 0; u < ST1_UNROLL; u++) {
-            int cc = base0 + u * 64 + lane;
+            int cc = u * 64 + lane;
             int frac = cc & 15, pos = cc >> 4;
             int tx = genx - r1 + pos / n1, ty = geny - r1 + pos % n1;
             int rx = sx + tx, ry = sy + ty;
-            ok[u] = cc < tot1 && rx >= 0 && rx < W && ry >= 0 && ry < H;
-            m[u] = 0;
-            if (ok[u]) m[u] = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, su);
+            m[u] = -1;
+            if (cc < tot1 && rx >= 0 && rx < W && ry >= 0 && ry < H)
+                m[u] = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, su);
             xy[u] = pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2));
         }
-#pragma unroll
-        for (int u = 0; u < ST1_UNROLL; u++)
-            if (base0 + u * 64 < tot1) wl_insert(L, 17, lane, ok[u], m[u], xy[u]);
+        select_topk<ST1_UNROLL>(m, xy, 17, lane, sel_lds, L);
+    } else {
+        for (int base = 0; base < tot1; base += 64) {
+            int cc = base + lane;
+            int frac = cc & 15, pos = cc >> 4;
+            int tx = genx - r1 + pos / n1, ty = geny - r1 + pos % n1;
+            int rx = sx + tx, ry = sy + ty;
+            bool ok = cc < tot1 && rx >= 0 && rx < W && ry >= 0 && ry < H;
+            int m = 0;
+            if (ok) m = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, su);
+            wl_insert(L, 17, lane, ok, m, pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2)));
+        }
     }
     int cnt = __popcll(__ballot(lane < 17 && L.m < 100000000));
     eval_list(L, 17, cnt, lane, Ps, ysz, W, H, sx, sy, src0, src1, mvpx, mvpy, bmin, bx, by);
 
     if (!d.basic && !(d.dbg & 32)) {
         // stage 2: re-rank the precomputed candidate set with the predictor weight (K = 33)
-        L.m = INF_M;
         int n2 = min(d.st2n[pidx], FER_ST2_CAP);
         const int2 *c2 = (const int2 *)(d.st2 + pidx * FER_ST2_CAP * 2);
-        for (int base0 = 0; base0 < n2; base0 += 64 * 3) {
-            int m[3], xy[3];
-            bool ok[3];
+        {
+            int m[FER_ST2_CAP / 64], xy[FER_ST2_CAP / 64];
 #pragma unroll
-            for (int u = 0; u < 3; u++) {
-                int cc = base0 + u * 64 + lane;
-                ok[u] = cc < n2;
-                m[u] = 0;
+            for (int u = 0; u < FER_ST2_CAP / 64; u++) {
+                int cc = u * 64 + lane;
+                m[u] = -1;
                 xy[u] = 0;
-                if (ok[u]) {
+                if (cc < n2) {
                     int2 e = c2[cc];
                     int tx = unp_x(e.x), ty = unp_y(e.x);
                     m[u] = (iabs(tx - genx) + iabs(ty - geny) + 4) * e.y;
                     xy[u] = pack_xy(tx * 4, ty * 4);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 3; u++)
-                if (base0 + u * 64 < n2) wl_insert(L, 33, lane, ok[u], m[u], xy[u]);
+            select_topk<FER_ST2_CAP / 64>(m, xy, 33, lane, sel_lds, L);
         }
         cnt = __popcll(__ballot(lane < 33 && L.m < 100000000));
         eval_list(L, 33, cnt, lane, Ps, ysz, W, H, sx, sy, src0, src1, mvpx, mvpy, bmin, bx, by);
