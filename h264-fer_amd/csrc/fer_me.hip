@@ -490,28 +490,36 @@ __device__ void predict_luma(const MvCtx &c, int part, int &ox, int &oy)
     oy = med3(my[0], my[1], my[2]);
 }
 
-// SAD of up to K list entries, 8 per round, and the ordered first-minimum cost update
-// (F/moestimation.cpp:460-468): cost = SAD + |mv - mvp|, strict < in list order.
-__device__ __forceinline__ void eval_list(const WList &L, int K, int cnt, int lane, const uint8_t *__restrict__ Ps,
+// SAD of up to K list entries (8 per round, all rounds' loads issued before any reduction) and
+// the ordered first-minimum cost update of F/moestimation.cpp:460-468: cost = SAD + |mv - mvp|,
+// strict < in list order, expressed as the minimum of (cost << 6 | list index).
+template <int K>
+__device__ __forceinline__ void eval_list(const WList &L, int cnt, int lane, const uint8_t *__restrict__ Ps,
                                           size_t ysz, int W, int H, int sx, int sy, uint32_t src0, uint32_t src1,
                                           int mvpx, int mvpy, int &bmin, int &bx, int &by)
 {
+    constexpr int ROUNDS = (K + 7) / 8;
     const int row = lane & 7;
-    for (int base = 0; base < cnt; base += 8) {
-        int j = base + (lane >> 3);
+    int best = 0x7fffffff, bestxy = 0;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        int j = r * 8 + (lane >> 3);
         int xy = __shfl(L.xy, j < K ? j : 0);
         int cxv = unp_x(xy), cyv = unp_y(xy);
         int sad = sad8_rows(Ps, ysz, W, H, sx, sy, cxv, cyv, row, src0, src1);
-        int cost = j < cnt ? sad + iabs(cxv - mvpx) + iabs(cyv - mvpy) : 2000000000;
-#pragma unroll
-        for (int g = 0; g < 8; g++) {
-            int cg = lane_bcast(cost, g * 8), xg = lane_bcast(cxv, g * 8), yg = lane_bcast(cyv, g * 8);
-            if (cg < bmin) {
-                bmin = cg;
-                bx = xg;
-                by = yg;
-            }
+        int key = j < cnt ? ((sad + iabs(cxv - mvpx) + iabs(cyv - mvpy)) << 6) | j : 0x7fffffff;
+        if (key < best) {
+            best = key;
+            bestxy = xy;
         }
+    }
+    int wmin = wave_min(best);
+    if (wmin != 0x7fffffff && (wmin >> 6) < bmin) {
+        int src = __ffsll((long long)__ballot(best == wmin)) - 1;
+        int xy = lane_bcast(bestxy, src);
+        bmin = wmin >> 6;
+        bx = unp_x(xy);
+        by = unp_y(xy);
     }
 }
 
@@ -652,7 +660,7 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
         }
     }
     int cnt = __popcll(__ballot(lane < 17 && L.m < 100000000));
-    eval_list(L, 17, cnt, lane, Ps, ysz, W, H, sx, sy, src0, src1, mvpx, mvpy, bmin, bx, by);
+    eval_list<17>(L, cnt, lane, Ps, ysz, W, H, sx, sy, src0, src1, mvpx, mvpy, bmin, bx, by);
 
     if (!d.basic && !(d.dbg & 32)) {
         // stage 2: re-rank the precomputed candidate set with the predictor weight (K = 33)
@@ -675,23 +683,22 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
             select_topk<FER_ST2_CAP / 64>(m, xy, 33, lane, sel_lds, L);
         }
         cnt = __popcll(__ballot(lane < 33 && L.m < 100000000));
-        eval_list(L, 33, cnt, lane, Ps, ysz, W, H, sx, sy, src0, src1, mvpx, mvpy, bmin, bx, by);
+        eval_list<33>(L, cnt, lane, Ps, ysz, W, H, sx, sy, src0, src1, mvpx, mvpy, bmin, bx, by);
         // stage 3: precomputed survivors of the centre-0 searches
         int n3 = (d.dbg & 64) ? 0 : d.st3n[pidx];
         const int *c3 = d.st3 + pidx * 33 * 3;
-        int cost = 2000000000, cxv = 0, cyv = 0;
+        int key = 0x7fffffff, cxy = 0;
         if (lane < n3) {
-            cxv = c3[lane * 3];
-            cyv = c3[lane * 3 + 1];
-            cost = c3[lane * 3 + 2] + iabs(cxv - mvpx) + iabs(cyv - mvpy);
+            int cxv = c3[lane * 3], cyv = c3[lane * 3 + 1];
+            key = ((c3[lane * 3 + 2] + iabs(cxv - mvpx) + iabs(cyv - mvpy)) << 6) | lane;
+            cxy = pack_xy(cxv, cyv);
         }
-        for (int g = 0; g < n3; g++) {
-            int cg = lane_bcast(cost, g), xg = lane_bcast(cxv, g), yg = lane_bcast(cyv, g);
-            if (cg < bmin) {
-                bmin = cg;
-                bx = xg;
-                by = yg;
-            }
+        int wmin = wave_min(key);
+        if (wmin != 0x7fffffff && (wmin >> 6) < bmin) {
+            int xy = lane_bcast(cxy, wmin & 63);
+            bmin = wmin >> 6;
+            bx = unp_x(xy);
+            by = unp_y(xy);
         }
     }
     if (lane == 0) {
