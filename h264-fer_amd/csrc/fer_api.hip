@@ -8,6 +8,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #define CK(x)                                                                                         \
@@ -161,6 +163,9 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     rc |= dalloc(c, &d.status, (size_t)S);
     rc |= dalloc(c, &d.sad, (size_t)S);
     rc |= dalloc(c, &d.stats, (size_t)5 * S);
+    rc |= dalloc(c, &d.dec_qp, nm);
+    rc |= dalloc(c, &d.dec_state, (size_t)4 * S);
+    rc |= dalloc(c, &d.dec_cac, (size_t)128 * S);
     int n = W * H;
     c->sort.tmp_bytes = fer_sort_tmp_bytes(n, S);
     rc |= dalloc(c, &c->sort.keys_in, (size_t)n * S);
@@ -720,6 +725,326 @@ extern "C" size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t
     if (hipStreamSynchronize(c->st) != hipSuccess) return 0;
     if (hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return n;
+}
+
+
+// =====================================================================================
+// Decoder driver: decode() / RBSP_decode() of F/fer_h264.cpp:26-53, F/rbsp_decoding.cpp:17-367.
+// Host side: Annex-B scan + emulation-prevention removal (F/nal.cpp:68-223), parameter sets and
+// slice header (F/headers_and_parameter_sets.cpp:245-298,398-537) -- a few dozen bits per NAL.
+// The macroblock loop runs on the device (fer_decode.hip).
+// =====================================================================================
+struct HostBR {
+    const uint8_t *b;
+    size_t n, pos;
+    unsigned bit()
+    {
+        size_t by = pos >> 3;
+        unsigned v = by < n ? (b[by] >> (7 - (pos & 7))) & 1u : 0u;
+        pos++;
+        return v;
+    }
+    unsigned bits(int k)
+    {
+        unsigned v = 0;
+        for (int i = 0; i < k; i++) v = (v << 1) | bit();
+        return v;
+    }
+    unsigned ue()
+    {
+        int z = 0;
+        while (z < 24 && bit() == 0) z++;  // the reference searches a 24-bit window (F/expgolomb.cpp:122)
+        return (1u << z) - 1u + bits(z);
+    }
+    int se()
+    {
+        int v = (int)ue();
+        return (v & 1) ? (v + 1) / 2 : -v / 2;
+    }
+};
+
+struct DecHdr {
+    int have_sps, W, H, log2_max_frame_num, poc_type, log2_max_poc_lsb;
+    int pic_init_qp, chroma_qp_offset, deblock_ctl, constrained_intra;
+    int mod_flag;
+};
+
+static void dec_parse_sps(DecHdr &h, HostBR &r)
+{
+    r.bits(24);
+    r.ue();
+    h.log2_max_frame_num = (int)r.ue() + 4;
+    h.poc_type = (int)r.ue();
+    h.log2_max_poc_lsb = 0;
+    if (h.poc_type == 0) {
+        h.log2_max_poc_lsb = (int)r.ue() + 4;
+    } else if (h.poc_type == 1) {
+        r.bits(1);
+        r.se();
+        r.se();
+        int n = (int)r.ue();
+        for (int i = 0; i < n; i++) r.se();
+    }
+    r.ue();
+    r.bits(1);
+    int wmb = (int)r.ue() + 1, hmu = (int)r.ue() + 1, fmo = (int)r.bits(1);
+    h.W = wmb * 16;
+    h.H = (2 - fmo) * hmu * 16;
+    h.have_sps = 1;
+}
+
+static void dec_parse_pps(DecHdr &h, HostBR &r)
+{
+    r.ue();
+    r.ue();
+    r.bits(2);
+    r.ue();
+    r.ue();
+    r.ue();
+    r.bits(3);
+    h.pic_init_qp = r.se() + 26;
+    r.se();
+    h.chroma_qp_offset = r.se();
+    h.deblock_ctl = (int)r.bits(1);
+    h.constrained_intra = (int)r.bits(1);
+}
+
+// slice header -> info[4] = {rbsp bytes, first bit of slice_data, slice_type % 5, SliceQPy}; returns 0 or error
+static int dec_parse_slice_header(DecHdr &h, const uint8_t *rbsp, size_t n, int nal_type, int ref_idc, uint32_t *info,
+                                  int &override_flag)
+{
+    HostBR r{rbsp, n, 0};
+    r.ue();
+    int st = (int)r.ue() % 5;
+    r.ue();
+    r.bits(h.log2_max_frame_num);
+    if (nal_type == 5) r.ue();
+    r.bits(h.log2_max_poc_lsb);
+    if (st == 0 || st == 1 || st == 3) {
+        override_flag = (int)r.bits(1);
+        if (override_flag && r.ue() > 0) return FERHIP_E_UNSUP;  // more than one reference index
+    }
+    if (st != 2 && st != 4) {
+        h.mod_flag = (int)r.bits(1);
+        if (h.mod_flag) return FERHIP_E_UNSUP;  // reference list modification
+    }
+    if (ref_idc != 0) {
+        if (nal_type == 5) {
+            r.bits(2);
+        } else if (r.bits(1)) {
+            unsigned op;
+            do {
+                op = r.ue();
+                if (op == 1 || op == 3) r.ue();
+                if (op == 2) r.ue();
+                if (op == 3 || op == 6) r.ue();
+                if (op == 4) r.ue();
+            } while (op != 0);
+        }
+    }
+    int qp = h.pic_init_qp + r.se();
+    if (h.deblock_ctl == 1) {
+        if (r.ue() != 1) {
+            r.se();
+            r.se();
+        }
+    }
+    if (st != 0 && st != 2) return FERHIP_E_UNSUP;
+    info[0] = (uint32_t)n;
+    info[1] = (uint32_t)r.pos;
+    info[2] = (uint32_t)st;
+    info[3] = (uint32_t)qp;
+    return 0;
+}
+
+// RBSP_decode for one slice NAL of every stream.  rbsp host [S][stride] (len 0 = no picture for
+// that stream), nal_type / nal_ref_idc per stream; slice headers are parsed with the parameter
+// sets given to ferhip_decode_set_params.
+struct DecParams {
+    DecHdr h;
+    std::vector<uint32_t> info;
+    uint8_t *d_rbsp;
+    size_t d_rbsp_cap;
+    uint32_t *d_info;
+};
+static DecParams *dec_params_of(ferhip_ctx *c);
+
+extern "C" int ferhip_decode_picture(ferhip_ctx *c, const uint8_t *rbsp, size_t stride, const uint32_t *len,
+                                     const int *nal_type, const int *nal_ref_idc)
+{
+    if (!c || !rbsp || !len || !nal_type) return FERHIP_E_ARG;
+    DecParams *dp = dec_params_of(c);
+    if (!dp || !dp->h.have_sps) return FERHIP_E_STATE;
+    FerDev &d = c->d;
+    const int S = d.S;
+    if (stride > dp->d_rbsp_cap / S) return FERHIP_E_ARG;
+    bool anyP = false, anyI = false;
+    for (int s = 0; s < S; s++) {
+        uint32_t *info = &dp->info[s * 4];
+        info[0] = info[1] = info[2] = info[3] = 0;
+        c->h_hdr[s * 4 + 3] = 2;
+        if (len[s] == 0) continue;
+        int ov = 0;
+        int rc = dec_parse_slice_header(dp->h, rbsp + (size_t)s * stride, len[s], nal_type[s], nal_ref_idc ? nal_ref_idc[s] : 1,
+                                        info, ov);
+        if (rc) return rc;
+        c->h_hdr[s * 4 + 3] = info[2];
+        anyP |= info[2] == 0;
+        anyI = true;  // intra macroblocks may appear in any slice type
+    }
+    d.dec_constrained_intra = dp->h.constrained_intra;
+    d.dec_chroma_qp_offset = dp->h.chroma_qp_offset;
+    // `frame` keeps the previous picture where the parser does not reach (F/rbsp_decoding.cpp:77)
+    CK(hipMemcpyAsync(c->planes[c->cur_set], c->planes[c->cur_set ^ 1], d.ysz * 3 / 2 * S, hipMemcpyDeviceToDevice, c->st));
+    CK(hipMemcpyAsync(dp->d_rbsp, rbsp, stride * S, hipMemcpyHostToDevice, c->st));
+    CK(hipMemcpyAsync(dp->d_info, dp->info.data(), sizeof(uint32_t) * 4 * S, hipMemcpyHostToDevice, c->st));
+    CK(hipMemcpyAsync(d.hdr, c->h_hdr, sizeof(uint32_t) * 4 * S, hipMemcpyHostToDevice, c->st));
+    fer_launch_decode(d, dp->d_rbsp, stride, dp->d_info, anyP, anyI, c->st);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(c->h_status, d.status, sizeof(int) * S, hipMemcpyDeviceToHost, c->st));
+    CK(hipStreamSynchronize(c->st));
+    for (int s = 0; s < S; s++)
+        if (c->h_status[s]) {
+            fprintf(stderr, "ferhip: stream %d decode status 0x%x\n", s, c->h_status[s]);
+            return (c->h_status[s] & FER_ERR_DEC_UNSUPPORTED) ? FERHIP_E_UNSUP : FERHIP_E_DEVICE;
+        }
+    c->cur_set ^= 1;  // the decoded picture becomes the reference (modificationProcess -> frameDeepCopy)
+    bind_planes(c);
+    for (int s = 0; s < S; s++) c->ss[s].have_dpb = 1;
+    return 0;
+}
+
+static std::vector<std::pair<ferhip_ctx *, DecParams *>> g_dec;
+static DecParams *dec_params_of(ferhip_ctx *c)
+{
+    for (auto &p : g_dec)
+        if (p.first == c) return p.second;
+    return nullptr;
+}
+
+// split an Annex-B stream like findNALstart/findNALend/parseNAL (4-byte start codes only)
+struct NalRef {
+    int type, ref_idc;
+    std::vector<uint8_t> rbsp;
+};
+static void split_stream(const uint8_t *s, size_t n, std::vector<NalRef> &out)
+{
+    size_t pos = 0;
+    for (;;) {
+        size_t st = (size_t)-1;
+        for (size_t i = pos; i + 3 < n; i++)
+            if (s[i] == 0 && s[i + 1] == 0 && s[i + 2] == 0 && s[i + 3] == 1) {
+                st = i + 4;
+                break;
+            }
+        if (st == (size_t)-1) break;
+        size_t en = n;
+        for (size_t i = st; i + 2 < n; i++)
+            if (s[i] == 0 && s[i + 1] == 0 && (s[i + 2] == 0 || s[i + 2] == 1)) {
+                en = i;
+                break;
+            }
+        pos = en;
+        if (en <= st) continue;
+        NalRef nal;
+        nal.ref_idc = (s[st] & 0x7f) >> 5;
+        nal.type = s[st] & 0x1f;
+        for (size_t i = st + 1; i < en; i++) {
+            if (i + 2 < en && s[i] == 0 && s[i + 1] == 0 && s[i + 2] == 3) {
+                nal.rbsp.push_back(s[i]);
+                nal.rbsp.push_back(s[i + 1]);
+                i += 2;
+            } else {
+                nal.rbsp.push_back(s[i]);
+            }
+        }
+        if (nal.rbsp.empty()) break;
+        out.push_back(std::move(nal));
+    }
+}
+
+// decode() for S Annex-B streams side by side.  All streams must carry the same picture size.
+// out: host [T][S][W*H*3/2] (T = max_pictures); pictures[s] = pictures decoded of stream s.
+extern "C" int ferhip_decode_streams(const uint8_t *const *streams, const size_t *lens, int S, uint8_t *out,
+                                     int max_pictures, int *pictures, int *W_out, int *H_out)
+{
+    if (!streams || !lens || S <= 0 || !pictures) return FERHIP_E_ARG;
+    std::vector<std::vector<NalRef>> nals(S);
+    DecHdr h;
+    memset(&h, 0, sizeof h);
+    for (int s = 0; s < S; s++) {
+        split_stream(streams[s], lens[s], nals[s]);
+        for (auto &n : nals[s]) {
+            HostBR r{n.rbsp.data(), n.rbsp.size(), 0};
+            DecHdr hs = h;
+            if (n.type == 7) {
+                dec_parse_sps(hs, r);
+                if (h.have_sps && (hs.W != h.W || hs.H != h.H)) return FERHIP_E_ARG;
+                h = hs;
+            } else if (n.type == 8) {
+                dec_parse_pps(hs, r);
+                h = hs;
+            }
+        }
+    }
+    if (!h.have_sps) return FERHIP_E_ARG;
+    if (W_out) *W_out = h.W;
+    if (H_out) *H_out = h.H;
+    ferhip_ctx *c = nullptr;
+    ferhip_params p = {26, 0, 16, 3, 1 << 30};
+    int rc = ferhip_create(&c, h.W, h.H, S, &p);
+    if (rc) return rc;
+    DecParams dp;
+    dp.h = h;
+    dp.info.assign((size_t)S * 4, 0);
+    size_t stride = 0;
+    for (int s = 0; s < S; s++)
+        for (auto &n : nals[s])
+            if (n.type == 1 || n.type == 5) stride = std::max(stride, n.rbsp.size());
+    stride = (stride + 15) & ~(size_t)15;
+    dp.d_rbsp_cap = stride * S + 16;
+    if (hipMalloc((void **)&dp.d_rbsp, dp.d_rbsp_cap) != hipSuccess || hipMalloc((void **)&dp.d_info, sizeof(uint32_t) * 4 * S) != hipSuccess) {
+        ferhip_destroy(c);
+        return FERHIP_E_HIP;
+    }
+    g_dec.push_back({c, &dp});
+    std::vector<size_t> cursor(S, 0);
+    std::vector<uint8_t> rb(stride * S);
+    std::vector<uint32_t> len(S);
+    std::vector<int> nt(S), nr(S);
+    size_t fsz = (size_t)h.W * h.H * 3 / 2;
+    for (int s = 0; s < S; s++) pictures[s] = 0;
+    rc = 0;
+    for (int t = 0;; t++) {
+        bool any = false;
+        for (int s = 0; s < S; s++) {
+            len[s] = 0;
+            nt[s] = nr[s] = 0;
+            while (cursor[s] < nals[s].size() && nals[s][cursor[s]].type != 1 && nals[s][cursor[s]].type != 5) cursor[s]++;
+            if (cursor[s] < nals[s].size()) {
+                NalRef &n = nals[s][cursor[s]++];
+                memcpy(rb.data() + (size_t)s * stride, n.rbsp.data(), n.rbsp.size());
+                len[s] = (uint32_t)n.rbsp.size();
+                nt[s] = n.type;
+                nr[s] = n.ref_idc;
+                any = true;
+            }
+        }
+        if (!any || (max_pictures > 0 && t >= max_pictures)) break;
+        rc = ferhip_decode_picture(c, rb.data(), stride, len.data(), nt.data(), nr.data());
+        if (rc) break;
+        if (out) {
+            rc = ferhip_get_recon(c, out + (size_t)t * S * fsz, 1);
+            if (rc) break;
+        }
+        for (int s = 0; s < S; s++)
+            if (len[s]) pictures[s]++;
+    }
+    g_dec.pop_back();
+    hipFree(dp.d_rbsp);
+    hipFree(dp.d_info);
+    ferhip_destroy(c);
+    return rc;
 }
 
 // ---- block-level KATs: forwardResidual / inverseResidual on the device

@@ -65,11 +65,18 @@ struct FerDev {
     int *status;         // [S] sticky error flags
     unsigned long long *sad; // [S] frame SAD for the IDR decision
     int *stats;          // [S][5] brojTipova
+    // decoder (row a19)
+    uint8_t *dec_qp;     // [S][nmb] QPy of every macroblock
+    int *dec_state;      // [S][4]: mb_qp_delta carried over, macroblocks parsed
+    int16_t *dec_cac;    // [S][2][4][16] persistent ChromaACLevel
+    int dec_constrained_intra, dec_chroma_qp_offset;
 };
 
 #define FER_ERR_ST2_OVERFLOW 1
 #define FER_ERR_ZERO_SUM 2
 #define FER_ERR_BITS_OVERFLOW 4
+#define FER_ERR_DEC_SYNTAX 8
+#define FER_ERR_DEC_UNSUPPORTED 16
 
 // ---------------------------------------------------------------- tables
 // CAVLC tables: H.264 Tables 9-5, 9-7..9-10 as (length, code); zig-zag; block origins.
@@ -136,6 +143,13 @@ static __constant__ uint8_t c_cbp_intra_code[48] = {3,  29, 30, 17, 31, 18, 37, 
 static __constant__ uint8_t c_cbp_inter_code[48] = {0,  2,  3,  7,  4,  8,  17, 13, 5,  18, 9,  14, 10, 15, 16, 11,
                                              1,  32, 33, 36, 34, 37, 44, 40, 35, 45, 38, 41, 39, 42, 43, 19,
                                              6,  24, 25, 20, 26, 21, 46, 28, 27, 47, 22, 29, 23, 30, 31, 12};
+// codeNum -> coded_block_pattern (Table 9-4, F/h264_globals.cpp:140-153)
+static __constant__ uint8_t c_code_cbp_intra[48] = {47, 31, 15, 0,  23, 27, 29, 30, 7,  11, 13, 14, 39, 43, 45, 46,
+                                             16, 3,  5,  10, 12, 19, 21, 26, 28, 35, 37, 42, 44, 1,  2,  4,
+                                             8,  17, 18, 20, 24, 6,  9,  22, 25, 32, 33, 34, 36, 40, 38, 41};
+static __constant__ uint8_t c_code_cbp_inter[48] = {0,  16, 1,  2,  4,  8,  32, 3,  5,  10, 12, 15, 47, 7,  11, 13,
+                                             14, 6,  9,  31, 35, 37, 42, 44, 33, 34, 36, 40, 39, 43, 45, 46,
+                                             17, 18, 20, 24, 19, 21, 26, 28, 23, 27, 29, 30, 22, 25, 38, 41};
 // neighbour A (left) / B (up) block of luma block k (6.4.10.4), chroma likewise
 static __constant__ uint8_t c_nbA[16] = {5, 0, 7, 2, 1, 4, 3, 6, 13, 8, 15, 10, 9, 12, 11, 14};
 static __constant__ uint8_t c_nbB[16] = {10, 11, 0, 1, 14, 15, 4, 5, 2, 3, 8, 9, 6, 7, 12, 13};

@@ -64,6 +64,7 @@ def load_library():
     lib.ferhip_read_buffer.restype = sz
     lib.ferhip_profile.argtypes = [vp, i]
     lib.ferhip_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), i]
+    lib.ferhip_decode_streams.argtypes = [C.POINTER(C.c_char_p), C.POINTER(sz), i, vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     lib.ferhip_forward_residual.argtypes = [i, vp, vp, i, sz]
     lib.ferhip_inverse_residual.argtypes = [i, vp, vp, i, sz]
     _lib = lib
@@ -222,3 +223,48 @@ def inverse_residual(qp, blocks, keep_dc=False):
     _chk(lib.ferhip_inverse_residual(qp, a.ctypes.data, out.ctypes.data, int(keep_dc), a.shape[0]),
          "ferhip_inverse_residual")
     return out
+
+
+def decode_streams(streams, max_pictures):
+    """decode() for a list of Annex-B byte strings of equal picture size -> (recon [T][S][fsz], pictures, W, H)."""
+    lib = load_library()
+    S = len(streams)
+    arr = (C.c_char_p * S)(*streams)
+    lens = (C.c_size_t * S)(*[len(s) for s in streams])
+    pics = (C.c_int * S)()
+    W, H = C.c_int(), C.c_int()
+    from . import shard
+    sps = [n for n in shard.split_nals(streams[0]) if (n[4] & 31) == 7][0]
+    w, h = _sps_size(sps[5:])
+    out = np.empty((max_pictures, S, w * h * 3 // 2), np.uint8)
+    _chk(lib.ferhip_decode_streams(arr, lens, S, out.ctypes.data, max_pictures, pics, C.byref(W), C.byref(H)),
+         "ferhip_decode_streams")
+    return out, list(pics), W.value, H.value
+
+
+def _sps_size(rbsp):
+    """width/height from an SPS RBSP (host-side helper for buffer sizing only)."""
+    bits = "".join(f"{b:08b}" for b in rbsp)
+    pos = [24]
+
+    def ue():
+        z = 0
+        while bits[pos[0]] == "0":
+            z += 1
+            pos[0] += 1
+        pos[0] += 1
+        v = int(bits[pos[0]:pos[0] + z] or "0", 2)
+        pos[0] += z
+        return (1 << z) - 1 + v
+
+    ue()
+    ue()
+    poc = ue()
+    if poc == 0:
+        ue()
+    ue()
+    pos[0] += 1
+    wmb = ue() + 1
+    hmu = ue() + 1
+    fmo = int(bits[pos[0]])
+    return wmb * 16, (2 - fmo) * hmu * 16

@@ -134,6 +134,18 @@ size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t cap);
 /* set the reference picture (dpb) directly, [S][W*H*3/2] host */
 int ferhip_set_reference(ferhip_ctx *c, const void *src);
 
+/* ---- decode twin (row a19): decode() / RBSP_decode(), F/fer_h264.cpp:26-53, F/rbsp_decoding.cpp:17 ----
+ * S Annex-B streams (4-byte start codes, as the reference reads them) of equal picture size are
+ * decoded side by side: slice_data parsing runs one wavefront per picture, reconstruction one
+ * wavefront per macroblock.  out (host, may be NULL): [max_pictures][S][W*H*3/2], picture t of
+ * stream s at (t*S + s)*W*H*3/2; pictures[s] = number decoded.  Syntax the GPU path does not
+ * implement (sub-8x8 partitions, I_PCM, several reference indices) returns FERHIP_E_UNSUP. */
+int ferhip_decode_streams(const uint8_t *const *streams, const size_t *lens, int nstreams, uint8_t *out,
+                          int max_pictures, int *pictures, int *width, int *height);
+/* one slice NAL per stream on an existing context (used by ferhip_decode_streams) */
+int ferhip_decode_picture(ferhip_ctx *c, const uint8_t *rbsp, size_t stride, const uint32_t *len, const int *nal_type,
+                          const int *nal_ref_idc);
+
 /* ---- block-level KAT surface: the reference's own signatures as batched device calls ----
  * forwardResidual(qP, c, r, Intra, Intra16x16OrChroma), F/quantizationTransform.h:
  * n blocks of 16 int32 (raster) in, 16 int32 out. */

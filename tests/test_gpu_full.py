@@ -163,3 +163,49 @@ def test_legacy_global_seam_matches_oracle(pkg, fo):
     ref, ref_rec = o.encode_stream(frames)
     assert bytes(out) == ref
     assert np.array_equal(np.stack(recs), ref_rec)
+
+
+def _oracle_decode(fo, stream):
+    n, frames, _ = fo.decode_stream_md5(stream)
+    return np.stack(frames)
+
+
+@pytest.mark.parametrize("case", ["qcif_i_2f_qp12", "qcif_ippp_4f_qp12_w16", "qcif_ippp_4f_qp28_w32", "qcif_skip_5f_qp12"])
+def test_gpu_decoder_matches_oracle_decoder_on_goldens(pkg, fo, case):
+    """BASELINE configs[4] at QCIF: CAVLC parse + dequant + inverse transform + prediction on the GPU,
+    bit-exact YUV against the oracle decoder (which reproduces the reference's md5 on drugi.264)."""
+    stream = (GOLD / f"{case}.264").read_bytes()
+    ref = _oracle_decode(fo, stream)
+    out, pics, W, H = pkg.decode_streams([stream, stream], ref.shape[0])
+    assert pics == [ref.shape[0]] * 2 and (W, H) == (176, 144)
+    for s in range(2):
+        assert np.array_equal(out[:, s], ref), case
+
+
+def test_gpu_decoder_1080p(pkg, fo):
+    """BASELINE configs[4]: 1080p decode of the IPPP stream."""
+    W, H, T = 1920, 1072, 3
+    frames = np.stack([pkg.gen_frame(W, H, t, 1234, 2) for t in range(T)])
+    g = pkg.FerHip(W, H, 1, qp=12, window=32, maxdiff=3, intra_every=30)
+    streams, rec = g.encode_streams(frames[:, None], want_recon=True)
+    g.close()
+    ref = _oracle_decode(fo, streams[0])
+    out, pics, w, h = pkg.decode_streams([streams[0]], T)
+    assert pics == [T] and (w, h) == (W, H)
+    assert np.array_equal(out[:, 0], ref)
+    assert np.array_equal(out[:, 0], rec[:, 0])  # decoder output == encoder reconstruction
+
+
+def test_gpu_decoder_reproduces_reference_md5_on_drugi(pkg):
+    """The reference's own fixture F/drugi.264 (x264 baseline, 640x480, 1000 pictures, intra MBs in P
+    slices, mb_qp_delta != 0) decoded on the GPU gives the md5 of the REFERENCE's output recorded in
+    SURVEY.md section 4 -- a pin of the HIP decode path that does not go through the oracle."""
+    stream = (GOLD / "drugi.264").read_bytes()
+    out, pics, W, H = pkg.decode_streams([stream], 1000)
+    assert pics == [1000] and (W, H) == (640, 480)
+    h = hashlib.md5()
+    h.update(b"YUV4MPEG2 C420jpeg W640 H480 F24:1 Ip A1:1\n")
+    for t in range(1000):
+        h.update(b"FRAME\n")
+        h.update(out[t, 0].tobytes())
+    assert h.hexdigest() == "346891974ac8cafcc6bb72706e34f950"
