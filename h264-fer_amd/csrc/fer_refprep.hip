@@ -67,77 +67,83 @@ __global__ __launch_bounds__(256) void k_interp(FerDev d)
 }
 
 // ------------------------------------------------------------------ k_features
-// One block = one 32x8 tile of positions, all 16 planes.  Per plane: separable box sums in LDS
-// (horizontal partial sums of every needed row, then 8 / 4 rows added per output).  Positions
-// beyond the picture replicate the last row/column (the reference pads its integral image by
-// 8).  Results are staged in LDS as one 192-byte record per position -- [frac][k0..k4,pad] --
-// and written with 16-byte stores, so a searcher gets the five features of one (position, frac)
-// with a single 12-byte load and the 16 fracs of neighbouring positions from contiguous lines.
-#define FT_W 32
-#define FT_H 8
-#define FT_REC 96  // uint16 per position: 16 fracs x 6
+// The five 8x8 box features of every (position, plane), F/moestimation.cpp:105-138, without an
+// integral image.  A wavefront owns a strip of 4 positions x FS_ROWS rows; lane = (position, plane):
+// 16 lanes of one position hold its 16 planes, so each output row is ONE contiguous 768-byte store
+// of finished 12-byte records [k0..k4,pad].  Per input row a lane reads the 8 samples x..x+7 of its
+// plane (three aligned dwords), reduces them with v_sad_u8 against zero to the three horizontal
+// partial sums, and keeps the last 8 rows in registers; vertical sums come straight from that ring.
+// Samples beyond the picture replicate the last row / column (the reference pads by 8).
+#define FS_ROWS 64
+__device__ __forceinline__ void feat_hsum(const uint8_t *__restrict__ row, int x, int W, int &h8, int &h4, int &hc)
+{
+    uint32_t lo, hi;
+    if (x + 7 < W) {
+        load_u8x8(row + x, lo, hi);
+    } else {
+        lo = hi = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            lo |= (uint32_t)row[min(x + j, W - 1)] << (8 * j);
+            hi |= (uint32_t)row[min(x + 4 + j, W - 1)] << (8 * j);
+        }
+    }
+    h4 = (int)__builtin_amdgcn_sad_u8(lo, 0u, 0u);
+    h8 = (int)__builtin_amdgcn_sad_u8(hi, 0u, (uint32_t)h4);
+    hc = (int)__builtin_amdgcn_sad_u8(hi & 0xffffu, 0u, __builtin_amdgcn_sad_u8(lo & 0xffffu, 0u, 0u));
+}
+
 __global__ __launch_bounds__(256) void k_features(FerDev d)
 {
-    __shared__ uint8_t tile[FT_H + 7][FT_W + 8];
-    __shared__ uint16_t h8[FT_H + 7][FT_W], h4[FT_H + 7][FT_W], hc[FT_H + 7][FT_W];
-    __shared__ __attribute__((aligned(16))) uint16_t rec[FT_W * FT_H][FT_REC];
-    const int s = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int xgroups = d.W >> 2, nstrips = (d.H + FS_ROWS - 1) / FS_ROWS;
+    long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long long)xgroups * nstrips * d.S) return;
+    const int xg = (int)(wid % xgroups);
+    const int strip = (int)((wid / xgroups) % nstrips);
+    const int s = (int)(wid / ((long long)xgroups * nstrips));
     if (d.hdr[s * 4 + 3] != 0) return;
-    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
-    const int tid = threadIdx.x;
-    const int tx = tid & (FT_W - 1), ty = tid / FT_W;
-    for (int f = 0; f < 16; f++) {
-        const uint8_t *P = d.interp + ((size_t)s * 16 + f) * d.ysz;
-        __syncthreads();
-        for (int i = tid; i < (FT_H + 7) * (FT_W + 7); i += 256) {
-            int r = i / (FT_W + 7), c = i % (FT_W + 7);
-            int sx = min(x0 + c, d.W - 1), sy = min(y0 + r, d.H - 1);
-            tile[r][c] = P[(size_t)sy * d.W + sx];
-        }
-        __syncthreads();
-        for (int i = tid; i < (FT_H + 7) * FT_W; i += 256) {
-            int r = i / FT_W, c = i % FT_W;
-            const uint8_t *q = &tile[r][c];
-            int a = q[0] + q[1], b = q[2] + q[3], cc = q[4] + q[5], e = q[6] + q[7];
-            h8[r][c] = (uint16_t)(a + b + cc + e);
-            h4[r][c] = (uint16_t)(a + b);
-            hc[r][c] = (uint16_t)(a + cc);
-        }
-        __syncthreads();
-        int k0 = 0, k1 = 0, k2 = 0, k3 = 0, k4 = 0;
+    const int f = lane & 15, x = xg * 4 + (lane >> 4);
+    const int W = d.W, H = d.H;
+    const uint8_t *P = d.interp + ((size_t)s * 16 + f) * d.ysz;
+    const int y0 = strip * FS_ROWS, y1 = min(y0 + FS_ROWS, H);  // output rows [y0, y1)
+    uint32_t *out = (uint32_t *)(d.feat + (size_t)s * 96 * d.ysz);
+    uint32_t *out0 = (uint32_t *)(d.feat0 + (size_t)s * 6 * d.ysz);
+    int h8[8], h4[8], hc[8];
+    for (int base = 0; base < FS_ROWS + 8; base += 8) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            int v8 = h8[ty + r][tx];
-            k0 += v8;
-            if (r < 4) k1 += v8;
-            k2 += h4[ty + r][tx];
-            if ((r & 3) < 2) k3 += v8;
-            k4 += hc[ty + r][tx];
-        }
-        uint16_t *o = &rec[tid][f * 6];
-        o[0] = (uint16_t)k0;
-        o[1] = (uint16_t)k1;
-        o[2] = (uint16_t)k2;
-        o[3] = (uint16_t)k3;
-        o[4] = (uint16_t)k4;
-        o[5] = 0;
-    }
-    __syncthreads();
-    // plane-0 copy, 12 bytes per position, for the wide integer search and the sort payload
-    const int x = x0 + tx, y = y0 + ty;
-    if (x < d.W && y < d.H) {
-        uint16_t *o0 = d.feat0 + ((size_t)s * d.ysz + (size_t)y * d.W + x) * 6;
+        for (int j = 0; j < 8; j++) {
+            const int y = y0 + base + j;  // input row (clamped), completes the window of output row y - 7
+            if (y - 7 < y1) {
+                feat_hsum(P + (size_t)min(y, H - 1) * W, x, W, h8[j], h4[j], hc[j]);
+                const int yo = y - 7;
+                if (yo >= y0) {
+                    // slot of window row r (picture row yo + r) is (j + 1 + r) & 7
+                    int k0 = 0, k2 = 0, k4 = 0;
 #pragma unroll
-        for (int k = 0; k < 6; k++) o0[k] = rec[tid][k];
-    }
-    const int vw = min(FT_W, d.W - x0);           // valid positions per tile row
-    const int row_vec = vw * (FT_REC * 2 / 16);   // 16-byte vectors per tile row
-    for (int v = tid; v < FT_H * row_vec; v += 256) {
-        int r = v / row_vec, o = v % row_vec;
-        if (y0 + r >= d.H) break;
-        const uint4 *src = (const uint4 *)&rec[r * FT_W][0] + o;
-        uint4 *dst = (uint4 *)(d.feat + ((size_t)s * d.ysz + (size_t)(y0 + r) * d.W + x0) * FT_REC) + o;
-        *dst = *src;
+                    for (int r = 0; r < 8; r++) {
+                        k0 += h8[r];
+                        k2 += h4[r];
+                        k4 += hc[r];
+                    }
+                    int k1 = h8[(j + 1) & 7] + h8[(j + 2) & 7] + h8[(j + 3) & 7] + h8[(j + 4) & 7];
+                    int k3 = h8[(j + 1) & 7] + h8[(j + 2) & 7] + h8[(j + 5) & 7] + h8[(j + 6) & 7];
+                    uint32_t a = (uint32_t)k0 | ((uint32_t)k1 << 16), b = (uint32_t)k2 | ((uint32_t)k3 << 16),
+                             c = (uint32_t)k4;
+                    size_t pos = (size_t)yo * W + x;
+                    uint32_t *o = out + (pos * 16 + f) * 3;
+                    o[0] = a;
+                    o[1] = b;
+                    o[2] = c;
+                    if (f == 0) {
+                        uint32_t *o0 = out0 + pos * 3;
+                        o0[0] = a;
+                        o0[1] = b;
+                        o0[2] = c;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -212,8 +218,8 @@ void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStr
     (void)types;
     dim3 gi((d.W + IT_W - 1) / IT_W, (d.H + IT_H - 1) / IT_H, d.S);
     hipLaunchKernelGGL(k_interp, gi, dim3(IT_W, IT_H), 0, st, d);
-    dim3 gf((d.W + FT_W - 1) / FT_W, (d.H + FT_H - 1) / FT_H, d.S);
-    hipLaunchKernelGGL(k_features, gf, dim3(256), 0, st, d);
+    long long fw = (long long)(d.W >> 2) * ((d.H + FS_ROWS - 1) / FS_ROWS) * d.S;
+    hipLaunchKernelGGL(k_features, dim3((unsigned)((fw + 3) / 4)), dim3(256), 0, st, d);
     int n = d.W * d.H;
     hipLaunchKernelGGL(k_sort_keys, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.keys_in, t.vals_in);
     size_t bytes = t.tmp_bytes;
