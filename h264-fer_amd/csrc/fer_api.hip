@@ -137,7 +137,7 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     rc |= dalloc(c, &d.feat, d.ysz * 96 * S);
     rc |= dalloc(c, &d.feat0, d.ysz * 6 * S);
     rc |= dalloc(c, &d.sort_pos, d.ysz * S);
-    rc |= dalloc(c, &d.sort_k12, d.ysz * S);
+    rc |= dalloc(c, &d.sort_rec, d.ysz * S);
     rc |= dalloc(c, &d.sort_k34, d.ysz * S);
     rc |= dalloc(c, &d.koliko, (size_t)16385 * S);
     size_t nm = (size_t)d.nmb * S;

@@ -36,7 +36,7 @@ struct FerDev {
     uint16_t *feat;      // [S][H][W][16][6]  k0..k4 + pad per (position, frac): one 12-byte load per candidate
     uint16_t *feat0;     // [S][H][W][6]      plane-0 copy for the wide integer search
     uint32_t *sort_pos;  // [S][W*H]  (tx << 16) | ty, ordered by (sum, tx, ty)
-    uint32_t *sort_k12;  // [S][W*H]  kar1 | kar2 << 16 of that position
+    uint2 *sort_rec;     // [S][W*H]  {.x = (tx << 16) | ty, .y = kar1 | kar2 << 16}: what the bucket walk filters on
     uint32_t *sort_k34;  // [S][W*H]  kar3 | kar4 << 16 of that position
     int *koliko;         // [S][16385] bucket start offsets
     // per-MB side information (a20)

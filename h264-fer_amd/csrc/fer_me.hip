@@ -173,8 +173,10 @@ __device__ __forceinline__ int sad8_rows(const uint8_t *__restrict__ Ps, size_t 
 // ------------------------------------------------------------------ k_me_pre
 #define ME_WIDE_LDS 1156  // (2*16+2)^2: WindowSize <= 32 takes the LDS route (4.6 KB per wave)
 #define ME_SEL_NB 25      // 64-candidate batches of stage 3 at WindowSize 32: 18 wide + 7 local
-__global__ __launch_bounds__(64) void k_me_pre(FerDev d)
+template <int WIN>  // WindowSize known at compile time (0 = read it from d): divisions by the window become shifts/muls
+__global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
 {
+    const int window = WIN ? WIN : d.window;
     __shared__ int wide_m[ME_WIDE_LDS];
     __shared__ int sel_lds[256];
     const int lane = threadIdx.x;
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
     WList L;
     L.m = INF_M;
     L.xy = 0;
-    const int R = d.window / 2, n = 2 * R + 1;
-    const int r2 = d.window / 16, n2w = 2 * r2 + 1, nloc = n2w * n2w * 16;
+    const int R = window / 2, n = 2 * R + 1;
+    const int r2 = window / 16, n2w = 2 * r2 + 1, nloc = n2w * n2w * 16;
     const uint16_t *F0 = d.feat0 + (size_t)s * 6 * ysz;
     const int wb = (n * n + 63) >> 6;  // batches of the wide search
     if (n * n <= ME_WIDE_LDS && wb + ((nloc + 63) >> 6) <= ME_SEL_NB && !(d.dbg & 3)) {
@@ -290,23 +292,31 @@ __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
 
     // ---- stage 2 candidate set: bucket walk of F/moestimation.cpp:470-496 (weight applied later)
     const int *kol = d.koliko + (size_t)s * 16385;
-    const uint32_t *spos = d.sort_pos + (size_t)s * ysz;
-    const uint32_t *sk12 = d.sort_k12 + (size_t)s * ysz;
+    const uint2 *srec = d.sort_rec + (size_t)s * ysz;
     const uint32_t *sk34 = d.sort_k34 + (size_t)s * ysz;
     int tren = 0;
     if (!d.basic && !(d.dbg & 8)) {
+        int kl0 = 0, kl1 = 0, kh0 = 0, kh1 = 0;
         for (int j = 0; j <= 180; j++) {
+            if ((j & 63) == 0) {  // bucket bounds of the next 64 steps on both sides, one lane per step
+                int al = su[0] - (j + lane), ah = su[0] + (j + lane);
+                bool vl = al >= 0 && al < 16384, vh = ah >= 0 && ah < 16384;
+                kl0 = vl ? kol[al] : 0;
+                kl1 = vl ? kol[al + 1] : 0;
+                kh0 = vh ? kol[ah] : 0;
+                kh1 = vh ? kol[ah + 1] : 0;
+            }
             for (int side = 0; side < 2; side++) {
                 int a = side ? su[0] + j : su[0] - j;
                 if (a < 0 || a >= 16384) continue;
-                int k0 = kol[a], k1 = kol[a + 1];
+                int k0 = lane_bcast(side ? kh0 : kl0, j & 63), k1 = lane_bcast(side ? kh1 : kl1, j & 63);
                 // A bucket is ordered by (tx, ty) and the filter needs |tx - sx| < 280: probe 64
                 // evenly spaced entries once and walk only the slice whose tx can pass (the exact
                 // filter below still decides, so the candidate set and its order are unchanged).
                 if (k1 - k0 > 128) {
                     int len = k1 - k0;
                     int pk = k0 + (int)(((long long)len * lane) >> 6);
-                    int ptx = (int)(spos[pk] >> 16);
+                    int ptx = (int)(srec[pk].x >> 16);
                     int nlo = __popcll(__ballot(ptx <= sx - 280));  // probes certainly left of the window
                     int nhi = __popcll(__ballot(ptx < sx + 280));   // probes not yet right of it
                     int s0 = nlo > 0 ? k0 + (int)(((long long)len * (nlo - 1)) >> 6) : k0;
@@ -317,30 +327,31 @@ __global__ __launch_bounds__(64) void k_me_pre(FerDev d)
                 for (int base = k0; base < k1; base += 64) {
                     int k = base + lane;
                     bool ok = false;
-                    int tx = 0, ty = 0, D = 0;
+                    int tx = 0, ty = 0, q1 = 0, q2 = 0;
                     if (k < k1) {
-                        uint32_t p = spos[k], q = sk12[k];
-                        int ax = (int)(p >> 16), ay = (int)(p & 0xffff);
-                        int q1 = (int)(q & 0xffff), q2 = (int)(q >> 16);
+                        uint2 e = srec[k];
+                        int ax = (int)(e.x >> 16), ay = (int)(e.x & 0xffff);
+                        q1 = (int)(e.y & 0xffff);
+                        q2 = (int)(e.y >> 16);
                         tx = ax - sx;
                         ty = ay - sy;
                         ok = iabs(tx) + iabs(ty) < 280 && iabs(q1 - su[1]) < 100 && iabs(q2 - su[2]) < 100;
-                        if (ok) {  // feature distance from the sorted payload: k0 == a, no scattered reads
-                            uint32_t r = sk34[k];
-                            int q3 = (int)(r & 0xffff), q4 = (int)(r >> 16);
-                            D = iabs(su[0] - a) + iabs(su[1] - q1) + iabs(su[0] - su[1] - a + q1) + iabs(su[2] - q2) +
-                                iabs(su[0] - su[2] - a + q2) + iabs(su[3] - q3) + iabs(su[0] - su[3] - a + q3) +
-                                iabs(su[4] - q4) + iabs(su[0] - su[4] - a + q4);
-                        }
                     }
                     unsigned long long mk = __ballot(ok);
-                    int rank = tren + __popcll(mk & ((1ull << lane) - 1));
-                    if (ok && rank < FER_ST2_CAP) {
-                        int *o = d.st2 + (pidx * FER_ST2_CAP + rank) * 2;
-                        o[0] = pack_xy(tx, ty);
-                        o[1] = D;
+                    if (mk) {
+                        int rank = tren + __popcll(mk & ((1ull << lane) - 1));
+                        if (ok && rank < FER_ST2_CAP) {  // feature distance from the sorted payload: k0 == a, no scattered reads
+                            uint32_t r = sk34[k];
+                            int q3 = (int)(r & 0xffff), q4 = (int)(r >> 16);
+                            int D = iabs(su[0] - a) + iabs(su[1] - q1) + iabs(su[0] - su[1] - a + q1) + iabs(su[2] - q2) +
+                                    iabs(su[0] - su[2] - a + q2) + iabs(su[3] - q3) + iabs(su[0] - su[3] - a + q3) +
+                                    iabs(su[4] - q4) + iabs(su[0] - su[4] - a + q4);
+                            int *o = d.st2 + (pidx * FER_ST2_CAP + rank) * 2;
+                            o[0] = pack_xy(tx, ty);
+                            o[1] = D;
+                        }
+                        tren += __popcll(mk);
                     }
-                    tren += __popcll(mk);
                 }
             }
             if (tren > 128) break;
@@ -392,8 +403,10 @@ __device__ __forceinline__ void eval_list(const WList &L, int cnt, int lane, con
 // and twice as many wavefronts are in flight per launch.  Partition 0 of a macroblock also makes
 // the P_Skip decision; partition 3 merges, derives mvd and does the final prediction + snapping.
 #define ST1_UNROLL 7
+template <int WIN>
 __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
 {
+    const int window = WIN ? WIN : d.window;
     __shared__ int sel_lds[256];
     const int lane = threadIdx.x;
     const int s = blockIdx.y;
@@ -495,7 +508,7 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
     WList L;
     L.m = INF_M;
     L.xy = 0;
-    const int r1 = d.window / 16, n1 = 2 * r1 + 1, tot1 = (d.dbg & 16) ? 0 : n1 * n1 * 16;
+    const int r1 = window / 16, n1 = 2 * r1 + 1, tot1 = (d.dbg & 16) ? 0 : n1 * n1 * 16;
     if (tot1 <= 64 * ST1_UNROLL) {
         int m[ST1_UNROLL], xy[ST1_UNROLL];
 #pragma unroll
@@ -643,7 +656,13 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
 
 void fer_launch_me_pre(const FerDev &d, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_me_pre, dim3(d.nmb * 4, d.S), dim3(64), 0, st, d);
+    dim3 g(d.nmb * 4, d.S);
+    if (d.window == 32)
+        hipLaunchKernelGGL(k_me_pre<32>, g, dim3(64), 0, st, d);
+    else if (d.window == 16)
+        hipLaunchKernelGGL(k_me_pre<16>, g, dim3(64), 0, st, d);
+    else
+        hipLaunchKernelGGL(k_me_pre<0>, g, dim3(64), 0, st, d);
 }
 
 int fer_me_resolve_launches(const FerDev &d) { return 2 * d.mbw + 3 * (2 * d.mbh - 1); }
@@ -653,5 +672,12 @@ void fer_launch_me_resolve(const FerDev &d, hipStream_t st)
     int gw = 2 * d.mbw, gh = 2 * d.mbh;
     int ndiag = gw + 3 * (gh - 1);
     int maxk = min(gh, (gw + 2) / 3);
-    for (int dg = 0; dg < ndiag; dg++) hipLaunchKernelGGL(k_me_resolve, dim3(maxk, d.S), dim3(64), 0, st, d, dg);
+    for (int dg = 0; dg < ndiag; dg++) {
+        if (d.window == 32)
+            hipLaunchKernelGGL(k_me_resolve<32>, dim3(maxk, d.S), dim3(64), 0, st, d, dg);
+        else if (d.window == 16)
+            hipLaunchKernelGGL(k_me_resolve<16>, dim3(maxk, d.S), dim3(64), 0, st, d, dg);
+        else
+            hipLaunchKernelGGL(k_me_resolve<0>, dim3(maxk, d.S), dim3(64), 0, st, d, dg);
+    }
 }

@@ -181,7 +181,7 @@ __global__ void k_sort_finish(FerDev d, const uint32_t *skeys, const uint32_t *s
         const uint32_t *r = (const uint32_t *)(d.feat0 + ((size_t)s * d.ysz + (size_t)ty * d.W + tx) * 6);
         uint32_t a = r[0], b = r[1], c = r[2];  // k0|k1<<16, k2|k3<<16, k4
         d.sort_pos[(size_t)s * n + i] = v;
-        d.sort_k12[(size_t)s * n + i] = (a >> 16) | (b << 16);
+        d.sort_rec[(size_t)s * n + i] = make_uint2(v, (a >> 16) | (b << 16));
         d.sort_k34[(size_t)s * n + i] = (b >> 16) | (c << 16);
     }
     if (i <= 16384) {  // koliko[a] = number of positions with sum < a
