@@ -29,6 +29,9 @@ struct ferhip_ctx {
     FerDev d;
     ferhip_params p;
     hipStream_t st;
+    hipStream_t st_hi;   // high-priority stream for the latency-bound per-diagonal chains
+    hipEvent_t ev_a, ev_b;
+    int device;  // HIP device the context lives on; every entry point re-selects it (callers may use any thread)
     std::vector<StreamState> ss;
     std::vector<void *> allocs;
     FerSortTmp sort;
@@ -51,19 +54,20 @@ struct ferhip_ctx {
 struct ProfScope {
     ferhip_ctx *c;
     int idx;
-    ProfScope(ferhip_ctx *c_, int phase, long launches) : c(c_), idx(-1)
+    hipStream_t s;
+    ProfScope(ferhip_ctx *c_, int phase, long launches, hipStream_t s_ = nullptr) : c(c_), idx(-1), s(s_ ? s_ : c_->st)
     {
         if (!c->prof) return;
         ferhip_ctx::Span sp{phase, nullptr, nullptr, launches};
         hipEventCreate(&sp.a);
         hipEventCreate(&sp.b);
-        hipEventRecord(sp.a, c->st);
+        hipEventRecord(sp.a, s);
         c->spans.push_back(sp);
         idx = (int)c->spans.size() - 1;
     }
     ~ProfScope()
     {
-        if (idx >= 0) hipEventRecord(c->spans[idx].b, c->st);
+        if (idx >= 0) hipEventRecord(c->spans[idx].b, s);
     }
 };
 
@@ -128,7 +132,15 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     d.dbg = getenv("FER_DBG") ? atoi(getenv("FER_DBG")) : 0;
     d.ysz = (size_t)W * H;
     d.csz = d.ysz / 4;
-    CK(hipStreamCreate(&c->st));
+    CK(hipGetDevice(&c->device));
+    {
+        int lo = 0, hi = 0;
+        CK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // numerically lower = higher priority
+        CK(hipStreamCreateWithPriority(&c->st, hipStreamNonBlocking, lo));
+        CK(hipStreamCreateWithPriority(&c->st_hi, hipStreamNonBlocking, hi));
+        CK(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
+    }
     size_t fsz = d.ysz * 3 / 2;
     int rc = 0;
     rc |= dalloc(c, &c->planes[0], fsz * S);
@@ -204,6 +216,7 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
 extern "C" void ferhip_destroy(ferhip_ctx *c)
 {
     if (!c) return;
+    (void)hipSetDevice(c->device);
     hipStreamSynchronize(c->st);
     for (void *p : c->allocs) hipFree(p);
     if (c->h_hdr) hipHostFree(c->h_hdr);
@@ -211,6 +224,9 @@ extern "C" void ferhip_destroy(ferhip_ctx *c)
     if (c->h_status) hipHostFree(c->h_status);
     if (c->h_sad) hipHostFree(c->h_sad);
     hipStreamDestroy(c->st);
+    hipStreamDestroy(c->st_hi);
+    hipEventDestroy(c->ev_a);
+    hipEventDestroy(c->ev_b);
     delete c;
 }
 
@@ -241,6 +257,7 @@ static int copy_frames(ferhip_ctx *c, uint8_t *set, const uint8_t *src, uint8_t 
 extern "C" int ferhip_set_frames(ferhip_ctx *c, const void *src, int host)
 {
     if (!c || !src) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
     int rc = copy_frames(c, c->planes[c->cur_set], (const uint8_t *)src, nullptr,
                          host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice);
     if (rc) return rc;
@@ -251,6 +268,7 @@ extern "C" int ferhip_set_frames(ferhip_ctx *c, const void *src, int host)
 extern "C" int ferhip_set_reference(ferhip_ctx *c, const void *src)
 {
     if (!c || !src) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
     int rc = copy_frames(c, c->planes[c->cur_set ^ 1], (const uint8_t *)src, nullptr, hipMemcpyHostToDevice);
     if (rc) return rc;
     CK(hipStreamSynchronize(c->st));
@@ -262,6 +280,7 @@ extern "C" int ferhip_set_reference(ferhip_ctx *c, const void *src)
 extern "C" int ferhip_get_recon(ferhip_ctx *c, void *dst, int host)
 {
     if (!c || !dst) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
     // after encode_picture the reconstruction is the reference set
     int rc = copy_frames(c, c->planes[c->cur_set ^ 1], nullptr, (uint8_t *)dst,
                          host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
@@ -469,6 +488,7 @@ static int decide_types(ferhip_ctx *c, const int *nal_type, std::vector<int> &nt
 extern "C" int ferhip_select_nal_type(ferhip_ctx *c, int *nal_type_out)
 {
     if (!c || !nal_type_out) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
     std::vector<int> nt;
     int rc = decide_types(c, nullptr, nt);
     if (rc) return rc;
@@ -502,8 +522,16 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
             fer_launch_me_pre(d, c->st);
         }
         {
-            ProfScope ps(c, FERHIP_PH_ME_RESOLVE, fer_me_resolve_launches(d));
-            fer_launch_me_resolve(d, c->st);
+            // the per-diagonal chain is latency bound: run it on the high-priority stream so that its small
+            // launches are dispatched ahead of other contexts' throughput kernels
+            CK(hipEventRecord(c->ev_a, c->st));
+            CK(hipStreamWaitEvent(c->st_hi, c->ev_a, 0));
+            {
+                ProfScope ps(c, FERHIP_PH_ME_RESOLVE, fer_me_resolve_launches(d), c->st_hi);
+                fer_launch_me_resolve(d, c->st_hi);
+            }
+            CK(hipEventRecord(c->ev_b, c->st_hi));
+            CK(hipStreamWaitEvent(c->st, c->ev_b, 0));
         }
         {
             ProfScope ps(c, FERHIP_PH_P_RESID, 1);
@@ -511,8 +539,14 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
         }
     }
     if (anyI) {
-        ProfScope ps(c, FERHIP_PH_INTRA, ndiag);
-        fer_launch_intra(d, c->st);
+        CK(hipEventRecord(c->ev_a, c->st));
+        CK(hipStreamWaitEvent(c->st_hi, c->ev_a, 0));
+        {
+            ProfScope ps(c, FERHIP_PH_INTRA, ndiag, c->st_hi);
+            fer_launch_intra(d, c->st_hi);
+        }
+        CK(hipEventRecord(c->ev_b, c->st_hi));
+        CK(hipStreamWaitEvent(c->st, c->ev_b, 0));
     }
     {
         ProfScope ps(c, FERHIP_PH_CAVLC, 1);
@@ -534,6 +568,7 @@ extern "C" int ferhip_encode_picture_dev(ferhip_ctx *c, int *nal_type, const uin
                                          const uint32_t **d_rbsp_len)
 {
     if (!c) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
     int rc = run_picture(c, nal_type);
     if (rc) return rc;
     if (d_rbsp) *d_rbsp = (const uint8_t *)c->d.bits;
@@ -545,6 +580,7 @@ extern "C" int ferhip_encode_picture_dev(ferhip_ctx *c, int *nal_type, const uin
 extern "C" int ferhip_encode_picture(ferhip_ctx *c, int *nal_type, uint8_t *rbsp, size_t rbsp_stride, uint32_t *rbsp_len)
 {
     if (!c || !rbsp || !rbsp_len) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
     int rc = run_picture(c, nal_type);
     if (rc) return rc;
     FerDev &d = c->d;
@@ -607,6 +643,7 @@ extern "C" int ferhip_encode_streams(ferhip_ctx *c, const uint8_t *frames, int n
 extern "C" int ferhip_get_stats(ferhip_ctx *c, int *out)
 {
     if (!c || !out) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
     CK(hipMemcpy(out, c->d.stats, sizeof(int) * 5 * c->d.S, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -614,6 +651,7 @@ extern "C" int ferhip_get_stats(ferhip_ctx *c, int *out)
 extern "C" int ferhip_status(ferhip_ctx *c, int *out)
 {
     if (!c || !out) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
     CK(hipMemcpy(out, c->d.status, sizeof(int) * c->d.S, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -621,6 +659,7 @@ extern "C" int ferhip_status(ferhip_ctx *c, int *out)
 extern "C" int ferhip_profile(ferhip_ctx *c, int enable)
 {
     if (!c) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
     c->prof = enable != 0;
     return 0;
 }
@@ -628,6 +667,7 @@ extern "C" int ferhip_profile(ferhip_ctx *c, int enable)
 extern "C" int ferhip_get_profile(ferhip_ctx *c, double *ms, long *launches, int reset)
 {
     if (!c || !ms || !launches) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
     CK(hipStreamSynchronize(c->st));
     for (auto &sp : c->spans) {
         float t = 0;
@@ -664,6 +704,7 @@ static void set_all_types(ferhip_ctx *c, int slice_type)
 extern "C" int ferhip_fill_interpolated(ferhip_ctx *c)
 {
     if (!c) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
     set_all_types(c, 0);
     fer_launch_refprep(c->d, c->sort, nullptr, c->st);
     CK(hipStreamSynchronize(c->st));
@@ -675,6 +716,7 @@ extern "C" int ferhip_fill_interpolated(ferhip_ctx *c)
 extern "C" int ferhip_inter_encoding(ferhip_ctx *c)
 {
     if (!c) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
     set_all_types(c, 0);
     if (!c->refprep_valid) fer_launch_refprep(c->d, c->sort, nullptr, c->st);
     c->refprep_valid = true;
@@ -694,6 +736,7 @@ extern "C" int ferhip_inter_encoding(ferhip_ctx *c)
 extern "C" size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t cap)
 {
     if (!c || !dst) return 0;
+    (void)hipSetDevice(c->device);
     FerDev &d = c->d;
     size_t nm = (size_t)d.nmb * d.S;
     const void *src = nullptr;
@@ -873,6 +916,7 @@ extern "C" int ferhip_decode_picture(ferhip_ctx *c, const uint8_t *rbsp, size_t 
                                      const int *nal_type, const int *nal_ref_idc)
 {
     if (!c || !rbsp || !len || !nal_type) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
     DecParams *dp = dec_params_of(c);
     if (!dp || !dp->h.have_sps) return FERHIP_E_STATE;
     FerDev &d = c->d;

@@ -424,6 +424,15 @@ __device__ __forceinline__ void mc_luma4(const uint8_t *__restrict__ R, const ui
     }
 }
 
+// XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (private L2s), so give every
+// XCD one contiguous eighth of the logical index space; neighbouring tiles then share an L2.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned n)
+{
+    unsigned per = n >> 3;
+    if (per == 0 || b >= per * 8) return b;  // tail (n not a multiple of 8) keeps its index
+    return (b & 7) * per + (b >> 3);
+}
+
 // ---------------------------------------------------------------- wave helpers
 // DPP (gfx9 row/wave controls) instead of ds_bpermute: the cross-lane steps sit on the critical
 // path of one-wave-per-macroblock code, where LDS-routed shuffles cost ~100 cycles each.

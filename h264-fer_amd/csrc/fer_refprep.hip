@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_features(FerDev d)
 {
     const int lane = threadIdx.x & 63;
     const int xgroups = d.W >> 2, nstrips = (d.H + FS_ROWS - 1) / FS_ROWS;
-    long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long long wid = (long long)xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     if (wid >= (long long)xgroups * nstrips * d.S) return;
     const int xg = (int)(wid % xgroups);
     const int strip = (int)((wid / xgroups) % nstrips);
