@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("FER_BENCH_STREAMS", "32")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("FER_BENCH_STREAMS", "64")))
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("FER_BENCH_CONTEXTS", "2")),
                     help="encoder contexts per GPU, each on its own HIP stream and host thread (streams are split evenly)")
     ap.add_argument("--cpu-frames", type=int, default=3, help="pictures of the CPU-baseline sample (0 = skip)")

@@ -14,6 +14,7 @@
 // One wavefront owns one macroblock; the candidate list of MEstimation
 // (F/moestimation.cpp:254-296) lives one slot per lane and is updated by ballot-ordered
 // insertion, which reproduces the reference's arrival-order tie breaking exactly.
+#include <stdlib.h>
 #include "fer_internal.h"
 #include "fer_mvpred.h"
 
