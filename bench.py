@@ -162,13 +162,21 @@ def main():
              "cavlc": S * nmb * GOP * args.steps}[dom]
     bytes_per_mb = {"me_pre": ME_BYTES_PER_MB, "me_resolve": ME_BYTES_PER_MB, "p_resid": 1152, "refprep": 384 + 16 * 256,
                     "intra": 768, "cavlc": 800}[dom]
+    # HBM traffic per launch from the committed PMC measurement (profiles/r01_traffic.json), scaled to the
+    # macroblocks one launch processes here; None when the file is absent
+    traffic = None
+    tj = ROOT / "profiles" / "r01_traffic.json"
+    if tj.exists():
+        per_mb = json.loads(tj.read_text())["bytes_per_mb"].get(dom)
+        if per_mb:
+            traffic = round(per_mb * units / max(launches, 1))
     avg_launch_s = (ms / 1e3) / max(launches, 1)
     achieved = (bytes_per_mb * units / max(launches, 1)) / avg_launch_s / 1e9 if ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": {"me_pre": "k_me_pre", "me_resolve": "k_me_resolve", "intra": "k_intra_mb",
                                            "refprep": "k_interp+k_features+sort", "cavlc": "k_cavlc",
                                            "p_resid": "k_p_resid"}[dom],
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": launches,
                 "bytes_per_mb": bytes_per_mb,
                 "phase_ms": {k: round(v[0], 2) for k, v in prof.items()}}
