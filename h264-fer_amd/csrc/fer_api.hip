@@ -167,6 +167,9 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     rc |= dalloc(c, &d.st3n, nm * 4);
     rc |= dalloc(c, &d.st2, nm * 4 * FER_ST2_CAP * 2);
     rc |= dalloc(c, &d.st2n, nm * 4);
+    rc |= dalloc(c, &d.chain, (size_t)64);
+    rc |= dalloc(c, &d.timing, (size_t)64);
+    rc |= dalloc(c, &d.chain64, nm * 4);
     rc |= dalloc(c, &d.mb_bits, ((size_t)d.nmb + 1) * S);
     d.bits_cap_words = ((size_t)d.nmb * 1024 + 4096) / 4;
     rc |= dalloc(c, &d.bits, d.bits_cap_words * S);
@@ -528,13 +531,15 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
             CK(hipStreamWaitEvent(c->st_hi, c->ev_a, 0));
             {
                 ProfScope ps(c, FERHIP_PH_ME_RESOLVE, fer_me_resolve_launches(d), c->st_hi);
+                d.serial = d.serial % 0x7ffffff0 + 1;  // validates this picture's words in chain64
                 fer_launch_me_resolve(d, c->st_hi);
             }
             CK(hipEventRecord(c->ev_b, c->st_hi));
             CK(hipStreamWaitEvent(c->st, c->ev_b, 0));
         }
         {
-            ProfScope ps(c, FERHIP_PH_P_RESID, 1);
+            ProfScope ps(c, FERHIP_PH_P_RESID, 2);
+            fer_launch_me_finish(d, c->st);
             fer_launch_p_resid(d, c->st);
         }
     }
@@ -726,8 +731,10 @@ extern "C" int ferhip_inter_encoding(ferhip_ctx *c)
     }
     {
         ProfScope ps(c, FERHIP_PH_ME_RESOLVE, fer_me_resolve_launches(c->d));
+        c->d.serial = c->d.serial % 0x7ffffff0 + 1;
         fer_launch_me_resolve(c->d, c->st);
     }
+    fer_launch_me_finish(c->d, c->st);
     CK(hipStreamSynchronize(c->st));
     CK(hipGetLastError());
     return 0;
@@ -753,6 +760,7 @@ extern "C" size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t
     case FERHIP_BUF_CBP: src = d.cbp; n = nm * 2; break;
     case FERHIP_BUF_TC: src = d.tc; n = nm * 24; break;
     case FERHIP_BUF_I4MODE: src = d.i4mode; n = nm * 16; break;
+    case FERHIP_BUF_TIMING: src = d.timing; n = 64 * 8; break;
     case FERHIP_BUF_CUR:
     case FERHIP_BUF_REF: {
         n = d.ysz * 3 / 2 * d.S;

@@ -234,6 +234,7 @@ __device__ void dec_derive_mvs(const FerDev &d, short *mvs, const int *mbt, int 
     c.mbw = d.mbw;
     c.cur = mb;
     c.type = type;
+    c.coh = false;
     short *o = mvs + (size_t)mb * 8;
     if (type == FER_P_SKIP) {
         int mx = 0, my = 0;

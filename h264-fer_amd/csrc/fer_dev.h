@@ -56,6 +56,10 @@ struct FerDev {
     int *st3n;           // [S][nmb][4]
     int *st2;            // [S][nmb][4][CAP][2] (tmpx & 0xffff) | tmpy << 16, D
     int *st2n;           // [S][nmb][4]
+    int *chain;          // row ticket of k_me_resolve
+    unsigned long long *chain64;  // [S][nmb][4] vector | picture serial << 32 | P_Skip << 63, see k_me_resolve
+    long long *timing;   // [64] in-kernel wall-clock sums of one probe wavefront (FER_DBG bit 7)
+    int serial;          // serial number of the picture being encoded (never 0)
     // entropy coding
     uint32_t *mb_bits;   // [S][nmb+1] bit sizes, then exclusive offsets
     uint32_t *bits;      // [S][bits_cap_words] RBSP, big-endian bit order
@@ -77,6 +81,7 @@ struct FerDev {
 #define FER_ERR_BITS_OVERFLOW 4
 #define FER_ERR_DEC_SYNTAX 8
 #define FER_ERR_DEC_UNSUPPORTED 16
+#define FER_ERR_CHAIN_TIMEOUT 32
 
 // ---------------------------------------------------------------- tables
 // CAVLC tables: H.264 Tables 9-5, 9-7..9-10 as (length, code); zig-zag; block origins.

@@ -55,26 +55,94 @@ __device__ __forceinline__ void wl_insert(WList &L, int K, int lane, bool valid,
 // ---- top-K of a candidate set by (metric, arrival order), without serial insertion ----
 // The reference's list (F/moestimation.cpp:277-291) ends up holding the K smallest candidates
 // ordered by metric, ties by arrival.  With candidate (u, lane) arriving at index u*64 + lane
-// that is a selection problem: binary-search the K-th smallest metric with ballot counts, take
-// everything below it plus the earliest arrivals equal to it, then rank the <= K winners.
-// v[u] < 0 marks an invalid candidate.  sel = 4*64 ints of LDS scratch owned by the wavefront.
-template <int NB>
-__device__ void select_topk(const int (&v)[NB], const int (&xy)[NB], int K, int lane, int *sel, WList &L)
+// that is a selection problem.  The code below sits on the serial chain of k_me_resolve, where one
+// wavefront runs alone on its SIMD and every dependent instruction costs its full latency, so
+// it is built from few, wide steps:
+//   1. T0 = the need-th smallest per-lane minimum -- an upper bound of the need-th smallest
+//      candidate (one rank computation over 64 LDS words),
+//   2. the candidates <= T0 are compacted in arrival order (typically 1.2-1.5 x need of them),
+//   3. their exact rank by (metric << 6 | compacted position) places the winners.
+// More than 64 survivors of step 2 or metrics >= 2^26 take the binary-search route instead.
+// v[u] < 0 marks an invalid candidate; pay(u) is the payload (packed vector) of the lane's
+// candidate u.  sel = 256 ints of 16-byte aligned LDS owned by the wavefront.
+__device__ __forceinline__ int lds_rank64(const unsigned *p, unsigned mine)
 {
-    int *key = sel, *kxy = sel + 64, *key2 = sel + 128, *kxy2 = sel + 192;
+    const uint4 *q = (const uint4 *)p;
+    int r = 0;
+#pragma unroll 4
+    for (int i = 0; i < 16; i++) {
+        uint4 k = q[i];
+        r += (int)(k.x < mine) + (int)(k.y < mine) + (int)(k.z < mine) + (int)(k.w < mine);
+    }
+    return r;
+}
+
+template <int NB, class PAY>
+__device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane, int *sel, WList &L, PAY pay)
+{
+    unsigned *A = (unsigned *)sel, *B = A + 64;
+    int *Ci = sel + 128, *Di = sel + 192;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int total = 0, lmin = 0x7fffffff, lmax = -1;
+    int cntl = 0, lmin = 0x7fffffff, lmax = -1;
 #pragma unroll
     for (int u = 0; u < NB; u++) {
         bool ok = v[u] >= 0;
-        total += __popcll(__ballot(ok));
+        cntl += ok;
         if (ok) lmin = min(lmin, v[u]);
         lmax = max(lmax, v[u]);
     }
+    const int total = wave_sum(cntl);
     const int need = min(K, total);
     L.m = INF_M;
     L.xy = 0;
     if (need == 0) return;
+    int c = 65;
+    if (!__any(lmax >= (1 << 26))) {
+        const unsigned mykey = lmin != 0x7fffffff ? ((unsigned)lmin << 6) | (unsigned)lane : 0xffffffffu;
+        A[lane] = mykey;
+        B[lane] = 0xffffffffu;
+        __syncthreads();
+        const int rk = lds_rank64(A, mykey);
+        const unsigned long long hit = __ballot(rk == need - 1);
+        int T0 = 0x7fffffff;  // fewer than `need` lanes hold anything: every candidate is needed
+        if (hit) {
+            unsigned tk = (unsigned)lane_bcast((int)mykey, __ffsll((long long)hit) - 1);
+            if (tk != 0xffffffffu) T0 = (int)(tk >> 6);
+        }
+        c = 0;
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            bool take = v[u] >= 0 && v[u] <= T0;
+            unsigned long long mk = __ballot(take);
+            int pos = c + __popcll(mk & lt);
+            if (take && pos < 64) {
+                B[pos] = ((unsigned)v[u] << 6) | (unsigned)pos;
+                Ci[pos] = pay(u);
+            }
+            c += __popcll(mk);
+        }
+    }
+    if (c <= 64) {
+        __syncthreads();
+        const unsigned mine = B[lane];
+        const int mypay = Ci[lane];
+        const int rk = lds_rank64(B, mine);
+        __syncthreads();
+        if (lane < c && rk < need) {
+            A[rk] = mine >> 6;
+            Di[rk] = mypay;
+        }
+        __syncthreads();
+        if (lane < need) {
+            L.m = (int)A[lane];
+            L.xy = Di[lane];
+        }
+        __syncthreads();
+        return;
+    }
+    // ---- general route: binary-search the need-th smallest metric with ballot counts, take everything
+    // below it plus the earliest arrivals equal to it, then rank the winners
+    int *key = sel, *kxy = sel + 64, *key2 = sel + 128, *kxy2 = sel + 192;
     int lo = wave_min(lmin), hi;
     if (__popcll(__ballot(lmin != 0x7fffffff)) >= need)
         hi = wave_max(lmin != 0x7fffffff ? lmin : -1);  // >= need candidates are <= the largest lane minimum
@@ -96,6 +164,7 @@ __device__ void select_topk(const int (&v)[NB], const int (&xy)[NB], int K, int 
     for (int u = 0; u < NB; u++) c_less += __popcll(__ballot(v[u] >= 0 && v[u] < T));
     const int take_eq = need - c_less;
     int nsel = 0, eq_seen = 0;
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < NB; u++) {
         bool ok = v[u] >= 0;
@@ -106,7 +175,7 @@ __device__ void select_topk(const int (&v)[NB], const int (&xy)[NB], int K, int 
         if (take) {
             int pos = nsel + __popcll(mt & lt);
             key[pos] = v[u];
-            kxy[pos] = xy[u];
+            kxy[pos] = pay(u);
         }
         nsel += __popcll(mt);
         eq_seen += __popcll(meq);
@@ -131,14 +200,17 @@ __device__ void select_topk(const int (&v)[NB], const int (&xy)[NB], int K, int 
 }
 
 // the 9-term feature distance of F/moestimation.cpp:267-276 from one 12-byte feature record
-__device__ __forceinline__ int feat_dist_rec(const uint16_t *__restrict__ rec, const int s[5])
+__device__ __forceinline__ int feat_dist_w(uint32_t a, uint32_t b, uint32_t c, const int s[5])
 {
-    const uint32_t *r = (const uint32_t *)rec;
-    uint32_t a = r[0], b = r[1], c = r[2];
     int k0 = (int)(a & 0xffff), k1 = (int)(a >> 16), k2 = (int)(b & 0xffff), k3 = (int)(b >> 16), k4 = (int)(c & 0xffff);
     return iabs(s[0] - k0) + iabs(s[1] - k1) + iabs(s[0] - s[1] - k0 + k1) + iabs(s[2] - k2) +
            iabs(s[0] - s[2] - k0 + k2) + iabs(s[3] - k3) + iabs(s[0] - s[3] - k0 + k3) + iabs(s[4] - k4) +
            iabs(s[0] - s[4] - k0 + k4);
+}
+__device__ __forceinline__ int feat_dist_rec(const uint16_t *__restrict__ rec, const int s[5])
+{
+    const uint32_t *r = (const uint32_t *)rec;
+    return feat_dist_w(r[0], r[1], r[2], s);
 }
 // ... at (frac, refy, refx) of the all-fracs array
 __device__ __forceinline__ int feat_dist(const uint16_t *__restrict__ Fs, size_t ysz, int W, int frac, int refy,
@@ -147,28 +219,71 @@ __device__ __forceinline__ int feat_dist(const uint16_t *__restrict__ Fs, size_t
     (void)ysz;
     return feat_dist_rec(Fs + (((size_t)refy * W + refx) * 16 + frac) * 6, s);
 }
+// Record fetch without control flow: coordinates are clamped into the picture so that the load
+// can always be issued (the caller masks candidates outside the picture afterwards).  Loads
+// under a branch are waited for one by one; a wavefront that runs alone on its SIMD cannot
+// afford that.
+struct FeatRec {
+    uint32_t a, b, c;
+};
+__device__ __forceinline__ FeatRec feat_load(const uint16_t *__restrict__ Fs, int W, int H, int frac, int refy, int refx)
+{
+    int y = iclamp(refy, 0, H - 1), x = iclamp(refx, 0, W - 1);
+    const uint32_t *r = (const uint32_t *)(Fs + (((size_t)y * W + x) * 16 + frac) * 6);
+    FeatRec f;
+    f.a = r[0];
+    f.b = r[1];
+    f.c = r[2];
+    return f;
+}
 
 // SAD of the 8x8 source block against interpolated plane (F/moestimation.cpp:175-195).
 // 8 lanes (rows) per candidate, 8 candidates per call: lane = cand*8 + row; src = the lane's
-// source row packed in two dwords.  Returns the full SAD in every lane of the group.
-__device__ __forceinline__ int sad8_rows(const uint8_t *__restrict__ Ps, size_t ysz, int W, int H, int xP, int yP,
-                                         int mvx, int mvy, int row, uint32_t s0, uint32_t s1)
+// source row packed in two dwords.  Split into an unconditional load (three aligned dwords that
+// cover the 8 reference samples; a row that runs over the right picture edge reads into the
+// next row, which stays inside the allocation) and the reduction, so that a caller can have the
+// loads of all its rounds in flight before the first reduction.
+struct SadRow {
+    uint32_t w0, w1, w2;
+    int sh, nv;  // byte offset of the first sample in w0; samples left of the right picture edge
+};
+__device__ __forceinline__ SadRow sad_row_load(const uint8_t *__restrict__ Ps, size_t ysz, int W, int H, int xP, int yP,
+                                               int mvx, int mvy, int row)
 {
     int xPi = iclamp(xP + (mvx >> 2), 0, W - 1), yPi = iclamp(yP + (mvy >> 2), 0, H - 1);
-    const uint8_t *R = Ps + (size_t)((mvx & 3) + (mvy & 3) * 4) * ysz + (size_t)min(yPi + row, H - 1) * W;
-    uint32_t r0, r1;
-    if (xPi + 7 < W) {
-        load_u8x8(R + xPi, r0, r1);
-    } else {  // right edge: the reference clamps each column (F/moestimation.cpp:189)
-        r0 = r1 = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            r0 |= (uint32_t)R[min(xPi + j, W - 1)] << (8 * j);
-            r1 |= (uint32_t)R[min(xPi + 4 + j, W - 1)] << (8 * j);
+    const uint8_t *p = Ps + (size_t)((mvx & 3) + (mvy & 3) * 4) * ysz + (size_t)min(yPi + row, H - 1) * W + xPi;
+    const uint32_t *a = (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
+    SadRow r;
+    r.w0 = a[0];
+    r.w1 = a[1];
+    r.w2 = a[2];
+    r.sh = (int)((uintptr_t)p & 3);
+    r.nv = W - xPi;
+    return r;
+}
+// returns the full SAD in every lane of the 8-lane group
+__device__ __forceinline__ int sad_row_reduce(const SadRow &r, uint32_t s0, uint32_t s1)
+{
+    uint32_t r0 = __builtin_amdgcn_alignbyte(r.w1, r.w0, (uint32_t)r.sh);
+    uint32_t r1 = __builtin_amdgcn_alignbyte(r.w2, r.w1, (uint32_t)r.sh);
+    if (__any(r.nv < 8)) {  // right edge: the reference clamps each column (F/moestimation.cpp:189)
+        if (r.nv < 8) {
+            unsigned long long v = ((unsigned long long)r1 << 32) | r0;
+            unsigned long long last = (v >> (8 * (r.nv - 1))) & 0xffull;
+            unsigned long long keep = (1ull << (8 * r.nv)) - 1ull;
+            v = (v & keep) | ((last * 0x0101010101010101ull) & ~keep);
+            r0 = (uint32_t)v;
+            r1 = (uint32_t)(v >> 32);
         }
     }
     int s = (int)__builtin_amdgcn_sad_u8(r1, s1, __builtin_amdgcn_sad_u8(r0, s0, 0));
     return oct_sum(s);
+}
+__device__ __forceinline__ int sad8_rows(const uint8_t *__restrict__ Ps, size_t ysz, int W, int H, int xP, int yP,
+                                         int mvx, int mvy, int row, uint32_t s0, uint32_t s1)
+{
+    SadRow r = sad_row_load(Ps, ysz, W, H, xP, yP, mvx, mvy, row);
+    return sad_row_reduce(r, s0, s1);
 }
 
 // ------------------------------------------------------------------ k_me_pre
@@ -179,7 +294,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
 {
     const int window = WIN ? WIN : d.window;
     __shared__ int wide_m[ME_WIDE_LDS];
-    __shared__ int sel_lds[256];
+    __shared__ __attribute__((aligned(16))) int sel_lds[256];
     const int lane = threadIdx.x;
     const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;
@@ -232,29 +347,32 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
             }
         }
         __syncthreads();
-        int v[ME_SEL_NB], xy[ME_SEL_NB];
+        int v[ME_SEL_NB];
 #pragma unroll
         for (int u = 0; u < ME_SEL_NB; u++) {
             v[u] = -1;
-            xy[u] = 0;
             if (u < wb) {
                 int c = u * 64 + lane;
-                if (c < n * n) {
-                    v[u] = wide_m[c];
-                    xy[u] = pack_xy((c / n - R) * 4, (c % n - R) * 4);
-                }
+                if (c < n * n) v[u] = wide_m[c];
             } else {
                 int c = (u - wb) * 64 + lane;
                 int frac = c & 15, pos = c >> 4;
                 int tx = pos / n2w - r2, ty = pos % n2w - r2;
                 int rx = sx + tx, ry = sy + ty;
-                if (c < nloc && rx >= 0 && rx < W && ry >= 0 && ry < H) {
+                if (c < nloc && rx >= 0 && rx < W && ry >= 0 && ry < H)
                     v[u] = (iabs(tx) + iabs(ty) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, su);
-                    xy[u] = pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2));
-                }
             }
         }
-        select_topk<ME_SEL_NB>(v, xy, 33, lane, sel_lds, L);
+        auto pay = [&](int u) {  // vector of the lane's candidate u
+            if (u < wb) {
+                int c = u * 64 + lane;
+                return pack_xy((c / n - R) * 4, (c % n - R) * 4);
+            }
+            int c = (u - wb) * 64 + lane;
+            int frac = c & 15, pos = c >> 4;
+            return pack_xy((pos / n2w - r2) * 4 + (frac & 3), (pos % n2w - r2) * 4 + (frac >> 2));
+        };
+        select_topk<ME_SEL_NB>(v, 33, lane, sel_lds, L, pay);
     } else {
         for (int base = 0; base < n * n && !(d.dbg & 1); base += 64) {
             int c = base + lane;
@@ -364,29 +482,41 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     }
 }
 
-// SAD of up to K list entries (8 per round, all rounds' loads issued before any reduction) and
-// the ordered first-minimum cost update of F/moestimation.cpp:460-468: cost = SAD + |mv - mvp|,
-// strict < in list order, expressed as the minimum of (cost << 6 | list index).
+// SAD of up to K list entries, 8 per round (lane = candidate*8 + row), and the lane's best
+// (cost << 6 | list index) over its rounds: cost = SAD + |mv - mvp| (F/moestimation.cpp:460-468).
+// No wave-level reduction in here, so that the loads of several lists can be in flight together.
 template <int K>
-__device__ __forceinline__ void eval_list(const WList &L, int cnt, int lane, const uint8_t *__restrict__ Ps,
-                                          size_t ysz, int W, int H, int sx, int sy, uint32_t src0, uint32_t src1,
-                                          int mvpx, int mvpy, int &bmin, int &bx, int &by)
+__device__ __forceinline__ void sad_keys(const WList &L, int cnt, int lane, const uint8_t *__restrict__ Ps, size_t ysz,
+                                         int W, int H, int sx, int sy, uint32_t src0, uint32_t src1, int mvpx, int mvpy,
+                                         int &best, int &bestxy)
 {
     constexpr int ROUNDS = (K + 7) / 8;
     const int row = lane & 7;
-    int best = 0x7fffffff, bestxy = 0;
+    SadRow rr[ROUNDS];
+    int xyr[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
         int j = r * 8 + (lane >> 3);
-        int xy = __shfl(L.xy, j < K ? j : 0);
-        int cxv = unp_x(xy), cyv = unp_y(xy);
-        int sad = sad8_rows(Ps, ysz, W, H, sx, sy, cxv, cyv, row, src0, src1);
+        xyr[r] = __shfl(L.xy, j < K ? j : 0);
+        rr[r] = sad_row_load(Ps, ysz, W, H, sx, sy, unp_x(xyr[r]), unp_y(xyr[r]), row);
+    }
+    best = 0x7fffffff;
+    bestxy = 0;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        int j = r * 8 + (lane >> 3);
+        int cxv = unp_x(xyr[r]), cyv = unp_y(xyr[r]);
+        int sad = sad_row_reduce(rr[r], src0, src1);
         int key = j < cnt ? ((sad + iabs(cxv - mvpx) + iabs(cyv - mvpy)) << 6) | j : 0x7fffffff;
         if (key < best) {
             best = key;
-            bestxy = xy;
+            bestxy = xyr[r];
         }
     }
+}
+// the strict-< first-minimum update of the reference, in list order, from per-lane bests
+__device__ __forceinline__ void take_best(int best, int bestxy, int &bmin, int &bx, int &by)
+{
     int wmin = wave_min(best);
     if (wmin != 0x7fffffff && (wmin >> 6) < bmin) {
         int src = __ffsll((long long)__ballot(best == wmin)) - 1;
@@ -398,60 +528,123 @@ __device__ __forceinline__ void eval_list(const WList &L, int cnt, int lane, con
 }
 
 // ------------------------------------------------------------------ k_me_resolve
-// One wavefront per 8x8 partition, launched per anti-diagonal gx + 3*gy of the PARTITION grid:
-// a partition needs the final vectors of its left, up, up-right and up-left neighbours only, so
-// the serial chain is one partition long (half of what a macroblock-level wavefront would need)
-// and twice as many wavefronts are in flight per launch.  Partition 0 of a macroblock also makes
-// the P_Skip decision; partition 3 merges, derives mvd and does the final prediction + snapping.
+// The neighbour-dependent part of the search is a chain: a partition needs the final vectors
+// of its left, up, up-right and up-left neighbours.  It runs as ONE persistent launch per
+// picture: one wavefront per (stream, row of 8x8 partitions) walks its row left to right and
+// follows the row above at the distance the prediction needs (3 partitions for partition 0,
+// whose P_Skip predictor reads the up-right MACROBLOCK; 2 for partitions 1 and 2; 1 for
+// partition 3).  Rows publish their progress through an agent-scope release store and wait
+// on the row above with an acquire load, so streams and rows advance independently instead
+// of meeting at a device-wide barrier (a kernel boundary) 639 times per picture.  Rows are
+// handed out by an atomic ticket in row-major order: the row a wavefront waits on was always
+// claimed earlier by a wavefront that is running or finished, so every wait terminates; a
+// bounded spin count turns anything unexpected into an error flag instead of a hang.
+//
+// Per partition the work is three rounds of loads:
+//   (1) everything that does not depend on the predictor (stage-2/3 candidate records of
+//       k_me_pre, box sums, source rows) -- requested one partition ahead,
+//   (2) the stage-1 feature records, (3) the SAD rows of the stage-1 and stage-2 survivors together.
+// Everything after the vector of the partition is known (merge, mvd, final prediction,
+// snapping) is not on any other partition's dependency chain and lives in k_me_finish.
 #define ST1_UNROLL 7
-template <int WIN>
-__global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
+#define RES_SPIN_LIMIT (1 << 23)
+
+struct ResPre {  // predictor-independent operands of one partition
+    int n2, n3;
+    int2 e2[FER_ST2_CAP / 64];
+    int c3x, c3y, c3s;
+    int su[5];
+    uint32_t src0, src1;
+};
+
+__device__ __forceinline__ void res_prefetch(const FerDev &d, int s, int gx, int gy, int lane, ResPre &p)
 {
+    const int mb = (gy >> 1) * d.mbw + (gx >> 1), part = (gy & 1) * 2 + (gx & 1);
+    const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
+    p.n2 = min(d.st2n[pidx], FER_ST2_CAP);
+    p.n3 = (d.dbg & 64) ? 0 : d.st3n[pidx];
+    const int2 *c2 = (const int2 *)(d.st2 + pidx * FER_ST2_CAP * 2);
+#pragma unroll
+    for (int u = 0; u < FER_ST2_CAP / 64; u++) p.e2[u] = c2[u * 64 + lane];  // slots >= n2 hold stale data, masked later
+    const int *c3 = d.st3 + pidx * 33 * 3;
+    p.c3x = p.c3y = p.c3s = 0;
+    if (lane < 33) {
+        p.c3x = c3[lane * 3];
+        p.c3y = c3[lane * 3 + 1];
+        p.c3s = c3[lane * 3 + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) p.su[k] = d.suma[pidx * 5 + k];
+    const uint8_t *Y = d.curY + (size_t)s * d.ysz;
+    const int row = lane & 7;
+    p.src0 = *(const uint32_t *)(Y + (size_t)(gy * 8 + row) * d.W + gx * 8);
+    p.src1 = *(const uint32_t *)(Y + (size_t)(gy * 8 + row) * d.W + gx * 8 + 4);
+}
+
+// Vectors travel between rows as self-validating 64-bit words in d.chain64 [S][nmb][4]:
+// bits 0-31 the packed vector, bits 32-62 the serial number of the picture, bit 63 "macroblock is
+// P_Skip".  A reader polls the words it needs until they carry the current serial, so no separate
+// flag, fence or store ordering is involved; loads and stores are agent scope (coherent across
+// the XCDs' L2s).
+#define CH_SKIP 0x80000000u
+struct ResNbr {      // neighbour vectors of one partition (packed), v* = available
+    bool vA, vB, vC, vD, vC16;
+    int A, B, C, D, C16;
+};
+
+__device__ __forceinline__ void nbr_to(int v, bool ok, int &mx, int &my, int &ref)
+{
+    mx = ok ? (int)(short)(v & 0xffff) : FER_MV_NA;
+    my = ok ? (v >> 16) : FER_MV_NA;
+    ref = ok ? 0 : -1;
+}
+// PredictMV_Luma without the directional rules (8x8 partitions and the P_Skip 16x16 predictor)
+__device__ __forceinline__ void predict_nbr(bool vA, int A, bool vB, int B, bool vC, int C, bool vD, int D, int &ox, int &oy)
+{
+    int mx[3], my[3], ref[3];
+    nbr_to(A, vA, mx[0], my[0], ref[0]);
+    nbr_to(B, vB, mx[1], my[1], ref[1]);
+    if (vC)
+        nbr_to(C, true, mx[2], my[2], ref[2]);
+    else
+        nbr_to(D, vD, mx[2], my[2], ref[2]);
+    predict_core(mx, my, ref, ox, oy);
+}
+
+// decision of partition (gx, gy): returns the packed vector; skip = the macroblock became P_Skip (partition 0 only)
+template <int WIN>
+__device__ __forceinline__ int resolve_part(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
+                                            int *sel_lds, bool &skip, bool probe, long long *tp)
+{
+#define RP_MARK(k)                        \
+    if (probe) {                          \
+        long long now_ = wall_clock64();  \
+        tp[k] += now_ - tm_;              \
+        tm_ = now_;                       \
+    }
+    long long tm_ = probe ? wall_clock64() : 0;
     const int window = WIN ? WIN : d.window;
-    __shared__ int sel_lds[256];
-    const int lane = threadIdx.x;
-    const int s = blockIdx.y;
-    if (d.hdr[s * 4 + 3] != 0) return;
-    // wavefront index f = gx + 3*gy: besides left / up / up-right / up-left, the P_Skip prediction of
-    // partition 0 reads the lower-left quadrant of the up-right MACROBLOCK, i.e. partition (gx+2, gy-1)
-    const int gw = d.mbw * 2, gh = d.mbh * 2;
-    int y_lo = diag - (gw - 1);
-    y_lo = y_lo > 0 ? (y_lo + 2) / 3 : 0;
-    const int gy = y_lo + blockIdx.x, gx = diag - 3 * gy;
-    if (gy >= gh || gx < 0 || gx >= gw) return;
     const int mbx = gx >> 1, mby = gy >> 1, part = (gy & 1) * 2 + (gx & 1);
     const int mb = mby * d.mbw + mbx;
     const int W = d.W, H = d.H, Wc = d.Wc, Hc = d.Hc;
     const size_t ysz = d.ysz, csz = d.csz;
     uint8_t *Y = d.curY + (size_t)s * ysz;
-    uint8_t *Cb = d.curCb + (size_t)s * csz, *Cr = d.curCr + (size_t)s * csz;
     const uint8_t *RY = d.refY + (size_t)s * ysz;
-    const uint8_t *RCb = d.refCb + (size_t)s * csz, *RCr = d.refCr + (size_t)s * csz;
     const uint8_t *Ps = d.interp + (size_t)s * 16 * ysz;
     const uint16_t *Fs = d.feat + (size_t)s * 96 * ysz;
-    int *mbt = d.mb_type + (size_t)s * d.nmb;
-    short *mvs = d.mv + (size_t)s * d.nmb * 8;
     const int xp = mbx << 4, yp = mby << 4;
-
-    MvCtx c;
-    c.mv = mvs;
-    c.mb_type = nullptr;
-    c.mbw = d.mbw;
-    c.cur = mb;
-    c.type = FER_P_SKIP;
-
-    // each lane owns 4 luma samples (lx..lx+3, ly) and one sample of each chroma plane
-    const int lx = (lane & 3) * 4, ly = lane >> 2;
-    const int cxl = lane & 7, cyl = lane >> 3;
+    const int sx = gx * 8, sy = gy * 8;
+    skip = false;
 
     if (part == 0) {
         // ---- P_Skip candidate, F/mode_pred.cpp:381-402 + F/moestimation.cpp:402-425
+        // each lane owns 4 luma samples (lx..lx+3, ly) and one sample of each chroma plane
+        const int lx = (lane & 3) * 4, ly = lane >> 2;
+        const int cxl = lane & 7, cyl = lane >> 3;
         int smx = 0, smy = 0;
         if (!(mb < d.mbw || mbx == 0)) {
-            int up = mb - d.mbw, lf = mb - 1;
-            bool zu = (mvs[(up * 4 + 2) * 2] | mvs[(up * 4 + 2) * 2 + 1]) == 0;
-            bool zl = (mvs[(lf * 4 + 1) * 2] | mvs[(lf * 4 + 1) * 2 + 1]) == 0;
-            if (!(zu || zl)) predict_luma(c, 0, smx, smy);
+            bool zu = N.B == 0, zl = N.A == 0;  // up MB quadrant 2, left MB quadrant 1
+            if (!(zu || zl)) predict_nbr(N.vA, N.A, N.vB, N.B, N.vC16, N.C16, N.vD, N.D, smx, smy);
         }
         int srcv[4], pred[4];
         uint32_t sv = *(const uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx);
@@ -470,60 +663,69 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
         for (int k = 0; k < 4; k++) exact = exact && iabs(srcv[k] - pred[k]) <= MAXDIFF;
         if (__all(exact)) {
             // P_Skip: reconstruction == prediction (F/inttransform.cpp:215-231)
+            uint8_t *Cb = d.curCb + (size_t)s * csz, *Cr = d.curCr + (size_t)s * csz;
+            const uint8_t *RCb = d.refCb + (size_t)s * csz, *RCr = d.refCr + (size_t)s * csz;
             *(uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx) =
                 (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
             Cb[(size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl] = (uint8_t)mc_chroma(RCb, Wc, Hc, xp / 2, yp / 2, cxl, cyl, smx, smy);
             Cr[(size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl] = (uint8_t)mc_chroma(RCr, Wc, Hc, xp / 2, yp / 2, cxl, cyl, smx, smy);
-            if (lane < 4) {
-                mvs[(mb * 4 + lane) * 2] = (short)smx;
-                mvs[(mb * 4 + lane) * 2 + 1] = (short)smy;
-            }
-            if (lane == 0) {
-                mbt[mb] = FER_P_SKIP;
-                atomicAdd(&d.stats[s * 5 + 0], 1);
-            }
-            return;
+            skip = true;
+            return pack_xy(smx, smy);
         }
-        if (lane == 0) mbt[mb] = FER_P_8x8ref0;  // also clears a P_Skip left by the previous picture
-    } else if (mbt[mb] == FER_P_SKIP) {
-        return;
     }
 
+    RP_MARK(0)
     // ---- search of this 8x8 partition as part of a P_8x8ref0 macroblock
-    c.type = FER_P_8x8ref0;
     int mvpx, mvpy;
-    predict_luma(c, part, mvpx, mvpy);
+    predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
     const int genx = mvpx >> 2, geny = mvpy >> 2;
-    const int sx = xp + (part & 1) * 8, sy = yp + (part >> 1) * 8;
-    const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
-    int su[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) su[k] = d.suma[pidx * 5 + k];
-    const int row = lane & 7;
-    const uint32_t src0 = *(const uint32_t *)(Y + (size_t)(sy + row) * W + sx);
-    const uint32_t src1 = *(const uint32_t *)(Y + (size_t)(sy + row) * W + sx + 4);
     int bx = 0, by = 0, bmin = 2000000000;
 
-    // stage 1: +-W/16 around the predictor, all 16 fractional planes (K = 17).  The feature
-    // records of ST1_UNROLL batches are fetched before the ordered insertion starts.
-    WList L;
-    L.m = INF_M;
-    L.xy = 0;
+    // ---- round (2): stage 1, +-W/16 around the predictor, all 16 fractional planes (K = 17)
+    WList L1, L2;
+    L1.m = L2.m = INF_M;
+    L1.xy = L2.xy = 0;
     const int r1 = window / 16, n1 = 2 * r1 + 1, tot1 = (d.dbg & 16) ? 0 : n1 * n1 * 16;
+    const bool st2on = !d.basic && !(d.dbg & 32);
+    // stage 2 (K = 33): the precomputed candidate set weighted by the distance to the predictor
+    int m2[FER_ST2_CAP / 64];
+#pragma unroll
+    for (int u = 0; u < FER_ST2_CAP / 64; u++) {
+        int cc = u * 64 + lane;
+        int tx = unp_x(P.e2[u].x), ty = unp_y(P.e2[u].x);
+        m2[u] = (st2on && cc < P.n2) ? (iabs(tx - genx) + iabs(ty - geny) + 4) * P.e2[u].y : -1;
+    }
+    auto pay2 = [&](int u) { return pack_xy(unp_x(P.e2[u].x) * 4, unp_y(P.e2[u].x) * 4); };
+    auto pay1 = [&](int u) {
+        int cc = u * 64 + lane;
+        int frac = cc & 15, pos = cc >> 4;
+        return pack_xy((genx - r1 + pos / n1) * 4 + (frac & 3), (geny - r1 + pos % n1) * 4 + (frac >> 2));
+    };
     if (tot1 <= 64 * ST1_UNROLL) {
-        int m[ST1_UNROLL], xy[ST1_UNROLL];
+        FeatRec fr[ST1_UNROLL];
 #pragma unroll
         for (int u = 0; u < ST1_UNROLL; u++) {
             int cc = u * 64 + lane;
             int frac = cc & 15, pos = cc >> 4;
+            fr[u] = feat_load(Fs, W, H, frac, sy + geny - r1 + pos % n1, sx + genx - r1 + pos / n1);
+        }
+        int m[ST1_UNROLL];
+#pragma unroll
+        for (int u = 0; u < ST1_UNROLL; u++) {
+            int cc = u * 64 + lane;
+            int pos = cc >> 4;
             int tx = genx - r1 + pos / n1, ty = geny - r1 + pos % n1;
             int rx = sx + tx, ry = sy + ty;
-            m[u] = -1;
-            if (cc < tot1 && rx >= 0 && rx < W && ry >= 0 && ry < H)
-                m[u] = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, su);
-            xy[u] = pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2));
+            bool ok = cc < tot1 && rx >= 0 && rx < W && ry >= 0 && ry < H;
+            int mm = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist_w(fr[u].a, fr[u].b, fr[u].c, P.su);
+            m[u] = ok ? mm : -1;
         }
-        select_topk<ST1_UNROLL>(m, xy, 17, lane, sel_lds, L);
+        RP_MARK(1)
+        // the stage-2 selection runs while the feature records above are in flight
+        select_topk<FER_ST2_CAP / 64>(m2, 33, lane, sel_lds, L2, pay2);
+        RP_MARK(2)
+        select_topk<ST1_UNROLL>(m, 17, lane, sel_lds, L1, pay1);
+        RP_MARK(3)
     } else {
         for (int base = 0; base < tot1; base += 64) {
             int cc = base + lane;
@@ -532,68 +734,174 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
             int rx = sx + tx, ry = sy + ty;
             bool ok = cc < tot1 && rx >= 0 && rx < W && ry >= 0 && ry < H;
             int m = 0;
-            if (ok) m = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, su);
-            wl_insert(L, 17, lane, ok, m, pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2)));
+            if (ok) m = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, P.su);
+            wl_insert(L1, 17, lane, ok, m, pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2)));
         }
+        select_topk<FER_ST2_CAP / 64>(m2, 33, lane, sel_lds, L2, pay2);
     }
-    int cnt = __popcll(__ballot(lane < 17 && L.m < 100000000));
-    eval_list<17>(L, cnt, lane, Ps, ysz, W, H, sx, sy, src0, src1, mvpx, mvpy, bmin, bx, by);
+    // ---- round (3): SAD rows of both survivor lists, then the ordered first-minimum over
+    // stage 1, stage 2, stage 3 (strict <, F/moestimation.cpp:460-520)
+    const int cnt1 = __popcll(__ballot(lane < 17 && L1.m < 100000000));
+    const int cnt2 = __popcll(__ballot(lane < 33 && L2.m < 100000000));
+    int b1, b1xy, b2, b2xy;
+    sad_keys<17>(L1, cnt1, lane, Ps, ysz, W, H, sx, sy, P.src0, P.src1, mvpx, mvpy, b1, b1xy);
+    sad_keys<33>(L2, cnt2, lane, Ps, ysz, W, H, sx, sy, P.src0, P.src1, mvpx, mvpy, b2, b2xy);
+    RP_MARK(4)
+    take_best(b1, b1xy, bmin, bx, by);
+    take_best(b2, b2xy, bmin, bx, by);
+    if (st2on) {
+        int key = 0x7fffffff;
+        if (lane < P.n3) key = ((P.c3s + iabs(P.c3x - mvpx) + iabs(P.c3y - mvpy)) << 6) | lane;
+        take_best(key, pack_xy(P.c3x, P.c3y), bmin, bx, by);
+    }
+    RP_MARK(5)
+#undef RP_MARK
+    return pack_xy(bx, by);
+}
 
-    if (!d.basic && !(d.dbg & 32)) {
-        // stage 2: re-rank the precomputed candidate set with the predictor weight (K = 33)
-        int n2 = min(d.st2n[pidx], FER_ST2_CAP);
-        const int2 *c2 = (const int2 *)(d.st2 + pidx * FER_ST2_CAP * 2);
-        {
-            int m[FER_ST2_CAP / 64], xy[FER_ST2_CAP / 64];
-#pragma unroll
-            for (int u = 0; u < FER_ST2_CAP / 64; u++) {
-                int cc = u * 64 + lane;
-                m[u] = -1;
-                xy[u] = 0;
-                if (cc < n2) {
-                    int2 e = c2[cc];
-                    int tx = unp_x(e.x), ty = unp_y(e.x);
-                    m[u] = (iabs(tx - genx) + iabs(ty - geny) + 4) * e.y;
-                    xy[u] = pack_xy(tx * 4, ty * 4);
-                }
+template <int WIN>
+__global__ __launch_bounds__(64, 4) void k_me_resolve(FerDev d)
+{
+    __shared__ __attribute__((aligned(16))) int sel_lds[256];
+    const int lane = threadIdx.x;
+    const int gw = d.mbw * 2, gh = d.mbh * 2;
+    // row ticket: rows of all streams in row-major order
+    int t = 0;
+    if (lane == 0) t = atomicAdd(d.chain, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    const int gy = t / d.S, s = t - gy * d.S;
+    if (gy >= gh) return;
+    if (d.hdr[s * 4 + 3] != 0) return;  // not a P picture: nobody waits on these rows
+    unsigned long long *chw = d.chain64 + (size_t)s * d.nmb * 4;
+    int *mbt = d.mb_type + (size_t)s * d.nmb;
+    short *mvs = d.mv + (size_t)s * d.nmb * 8;
+    const unsigned serial = (unsigned)d.serial & 0x7fffffffu;
+
+#ifdef FER_PROBE
+    const bool probe = (d.dbg & 128) && s == 0 && gy == gh / 2;  // one wavefront reports where its time goes
+#else
+    const bool probe = false;
+#endif
+    long long tacc[4] = {0, 0, 0, 0}, tmark = 0, tp[6] = {0, 0, 0, 0, 0, 0};
+    int prevw = 0;  // vector of the previous partition of this row (the left neighbour A)
+    bool skip = false, timeout = false;
+    for (int gx = 0; gx < gw; gx++) {
+        const int part = (gy & 1) * 2 + (gx & 1);
+        const int mb = (gy >> 1) * d.mbw + (gx >> 1);
+        if (probe) tmark = wall_clock64();
+        // the lane id is made opaque per iteration: otherwise dozens of lane-derived constants of the loop body
+        // are hoisted out of the loop and spilled
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        ResPre cur;  // requested before the neighbours are polled: both round trips overlap
+        res_prefetch(d, s, gx, gy, ln, cur);
+        // neighbours in the row above: lane 0 = B, 1 = C, 2 = D, 3 = C of the 16x16 (P_Skip) predictor
+        const int x = (part & 1) * 8, y = (part >> 1) * 8;
+        bool val = false;
+        int mbN = 0, q = 0;
+        if (lane < 3 || (lane == 3 && part == 0)) {
+            int nx = lane == 0 ? x : (lane == 1 ? x + 8 : (lane == 2 ? x - 1 : 16));
+            int ny = lane == 3 ? -1 : y - 1;
+            nbr_locate(d.mbw, mb, nx, ny, val, mbN, q);
+        }
+        unsigned wl = 0, wh = 0;
+        for (int it = 0;; it++) {
+            bool ok = true;
+            if (val) {
+                unsigned long long w = __hip_atomic_load(chw + (size_t)mbN * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wl = (unsigned)w;
+                wh = (unsigned)(w >> 32);
+                ok = (wh & 0x7fffffffu) == serial;
             }
-            select_topk<FER_ST2_CAP / 64>(m, xy, 33, lane, sel_lds, L);
+            if (__all(ok)) break;
+            if (it > RES_SPIN_LIMIT || timeout) {  // never expected: flag it and stop waiting so that the grid drains
+                timeout = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
         }
-        cnt = __popcll(__ballot(lane < 33 && L.m < 100000000));
-        eval_list<33>(L, cnt, lane, Ps, ysz, W, H, sx, sy, src0, src1, mvpx, mvpy, bmin, bx, by);
-        // stage 3: precomputed survivors of the centre-0 searches
-        int n3 = (d.dbg & 64) ? 0 : d.st3n[pidx];
-        const int *c3 = d.st3 + pidx * 33 * 3;
-        int key = 0x7fffffff, cxy = 0;
-        if (lane < n3) {
-            int cxv = c3[lane * 3], cyv = c3[lane * 3 + 1];
-            key = ((c3[lane * 3 + 2] + iabs(cxv - mvpx) + iabs(cyv - mvpy)) << 6) | lane;
-            cxy = pack_xy(cxv, cyv);
+        if (probe) {
+            long long now = wall_clock64();
+            tacc[0] += now - tmark;
+            tmark = now;
         }
-        int wmin = wave_min(key);
-        if (wmin != 0x7fffffff && (wmin >> 6) < bmin) {
-            int xy = lane_bcast(cxy, wmin & 63);
-            bmin = wmin >> 6;
-            bx = unp_x(xy);
-            by = unp_y(xy);
+        ResNbr N;
+        const unsigned long long vm = __ballot(val);
+        N.vA = gx > 0;
+        N.A = prevw;
+        N.vB = vm & 1;
+        N.vC = (vm >> 1) & 1;
+        N.vD = (vm >> 2) & 1;
+        N.vC16 = (vm >> 3) & 1;
+        N.B = lane_bcast((int)wl, 0);
+        N.C = lane_bcast((int)wl, 1);
+        N.D = lane_bcast((int)wl, 2);
+        N.C16 = lane_bcast((int)wl, 3);
+        if (part == 2) {  // P_Skip was decided by the row above (B is quadrant 0 of this macroblock)
+            skip = (lane_bcast((int)wh, 0) & CH_SKIP) != 0;
+            if (skip) prevw = N.B;
         }
+        if (part == 0 || !skip) {
+            bool sk;
+            int r = resolve_part<WIN>(d, s, gx, gy, ln, cur, N, sel_lds, sk, probe, tp);
+            prevw = r;
+            if (probe) {
+                long long now = wall_clock64();
+                tacc[1] += now - tmark;
+                tmark = now;
+            }
+            unsigned long long w = (unsigned)r | ((unsigned long long)(serial | (sk ? CH_SKIP : 0u)) << 32);
+            if (part == 0) {
+                skip = sk;
+                if (lane == 0) mbt[mb] = sk ? FER_P_SKIP : FER_P_8x8ref0;  // also clears a P_Skip left by the previous picture
+                if (sk && lane == 0) atomicAdd(&d.stats[s * 5 + 0], 1);
+            }
+            const int nq = sk ? 4 : 1, q0 = sk ? 0 : part;
+            if (lane < nq) {
+                *(int *)(mvs + ((size_t)mb * 4 + q0 + lane) * 2) = r;
+                __hip_atomic_store(chw + (size_t)mb * 4 + q0 + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (probe) tacc[2] += wall_clock64() - tmark;
     }
-    if (lane == 0) {
-        mvs[(mb * 4 + part) * 2] = (short)bx;
-        mvs[(mb * 4 + part) * 2 + 1] = (short)by;
+    if (probe && lane == 0) {
+        for (int k = 0; k < 3; k++) d.timing[k] = tacc[k];
+        d.timing[3] = gw;
+        for (int k = 0; k < 6; k++) d.timing[4 + k] = tp[k];
     }
-    if (part != 3) return;
+    if (timeout && lane == 0) atomicOr(&d.status[s], FER_ERR_CHAIN_TIMEOUT);
+}
 
-    // ---- last partition: merge, mvd, final prediction, snapping (F/moestimation.cpp:529-584)
+// ------------------------------------------------------------------ k_me_finish
+// After every partition vector of the picture is final: partition merge, mvd, final motion
+// compensation and source snapping of one macroblock per wavefront (F/moestimation.cpp:529-584).
+// Nothing in here is read by another macroblock's decision, so all macroblocks run in parallel.
+__global__ __launch_bounds__(64) void k_me_finish(FerDev d)
+{
+    const int lane = threadIdx.x;
+    const int s = blockIdx.y, mb = blockIdx.x;
+    if (d.hdr[s * 4 + 3] != 0) return;
+    int *mbt = d.mb_type + (size_t)s * d.nmb;
+    if (mbt[mb] == FER_P_SKIP) return;
+    const int mbx = mb % d.mbw, mby = mb / d.mbw;
+    const int W = d.W, H = d.H, Wc = d.Wc, Hc = d.Hc;
+    const size_t ysz = d.ysz, csz = d.csz;
+    uint8_t *Y = d.curY + (size_t)s * ysz;
+    uint8_t *Cb = d.curCb + (size_t)s * csz, *Cr = d.curCr + (size_t)s * csz;
+    const uint8_t *RY = d.refY + (size_t)s * ysz;
+    const uint8_t *RCb = d.refCb + (size_t)s * csz, *RCr = d.refCr + (size_t)s * csz;
+    const uint8_t *Ps = d.interp + (size_t)s * 16 * ysz;
+    const short *mvs = d.mv + (size_t)s * d.nmb * 8;
+    const int xp = mbx << 4, yp = mby << 4;
+    const int lx = (lane & 3) * 4, ly = lane >> 2;
+    const int cxl = lane & 7, cyl = lane >> 3;
+
     int mvx[4], mvy[4];
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 4; i++) {
         mvx[i] = mvs[(mb * 4 + i) * 2];
         mvy[i] = mvs[(mb * 4 + i) * 2 + 1];
     }
-    mvx[3] = bx;
-    mvy[3] = by;
-    __threadfence_block();
     int type = FER_P_8x8ref0, stat = 4;
     if (mvx[0] == mvx[1] && mvx[0] == mvx[2] && mvx[0] == mvx[3] && mvy[0] == mvy[1] && mvy[0] == mvy[2] &&
         mvy[0] == mvy[3]) {
@@ -606,9 +914,14 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
         type = FER_P_8x16;
         stat = 3;
     }
-    // mvd under the final type.  Own earlier partitions are read from d.mv: quadrant 3 was just
-    // stored by lane 0; no prediction of partition <= 3 ever reads quadrant 3 of its own MB.
+    // mvd under the final type (own earlier partitions are read from d.mv like the neighbours)
+    MvCtx c;
+    c.mv = mvs;
+    c.mb_type = nullptr;
+    c.mbw = d.mbw;
+    c.cur = mb;
     c.type = type;
+    c.coh = false;
     int np = type == FER_P_L0_16x16 ? 1 : (type == FER_P_8x8ref0 ? 4 : 2);
     int dvx[4] = {0, 0, 0, 0}, dvy[4] = {0, 0, 0, 0};
     for (int i = 0; i < np; i++) {
@@ -627,32 +940,35 @@ __global__ __launch_bounds__(64) void k_me_resolve(FerDev d, int diag)
         mbt[mb] = type;
         atomicAdd(&d.stats[s * 5 + stat], 1);
     }
-    {
-        int srcv[4];
-        uint32_t sv = *(const uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx);
+    int srcv[4];
+    uint32_t sv = *(const uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx);
 #pragma unroll
-        for (int k = 0; k < 4; k++) srcv[k] = (sv >> (8 * k)) & 0xff;
-        int MAXDIFF = d.maxdiff_set;
-        if (d.maxdiff_set == -1) {
-            int mean = wave_sum(srcv[0] + srcv[1] + srcv[2] + srcv[3]) / 256;
-            int dev = wave_sum(iabs(srcv[0] - mean) + iabs(srcv[1] - mean) + iabs(srcv[2] - mean) + iabs(srcv[3] - mean));
-            MAXDIFF = dev / 256;
-            if (MAXDIFF < 3) MAXDIFF = 3;
-        }
-        int q = (ly >> 3) * 2 + (lx >> 3);
-        int pf[4];
-        mc_luma4(RY, Ps, ysz, W, H, xp, yp, lx, ly, mvx[q], mvy[q], pf);
-        uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) packed |= (uint32_t)(iabs(srcv[k] - pf[k]) < MAXDIFF ? pf[k] : srcv[k]) << (8 * k);
-        *(uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx) = packed;
-        int qc = (cyl >> 2) * 2 + (cxl >> 2);
-        size_t co = (size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl;
-        int pb = mc_chroma(RCb, Wc, Hc, xp / 2, yp / 2, cxl, cyl, mvx[qc], mvy[qc]);
-        int pr = mc_chroma(RCr, Wc, Hc, xp / 2, yp / 2, cxl, cyl, mvx[qc], mvy[qc]);
-        if (iabs((int)Cb[co] - pb) <= MAXDIFF) Cb[co] = (uint8_t)pb;
-        if (iabs((int)Cr[co] - pr) <= MAXDIFF) Cr[co] = (uint8_t)pr;
+    for (int k = 0; k < 4; k++) srcv[k] = (sv >> (8 * k)) & 0xff;
+    int MAXDIFF = d.maxdiff_set;
+    if (d.maxdiff_set == -1) {
+        int mean = wave_sum(srcv[0] + srcv[1] + srcv[2] + srcv[3]) / 256;
+        int dev = wave_sum(iabs(srcv[0] - mean) + iabs(srcv[1] - mean) + iabs(srcv[2] - mean) + iabs(srcv[3] - mean));
+        MAXDIFF = dev / 256;
+        if (MAXDIFF < 3) MAXDIFF = 3;
     }
+    int q = (ly >> 3) * 2 + (lx >> 3);
+    int pf[4];
+    mc_luma4(RY, Ps, ysz, W, H, xp, yp, lx, ly, mvx[q], mvy[q], pf);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) packed |= (uint32_t)(iabs(srcv[k] - pf[k]) < MAXDIFF ? pf[k] : srcv[k]) << (8 * k);
+    *(uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx) = packed;
+    int qc = (cyl >> 2) * 2 + (cxl >> 2);
+    size_t co = (size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl;
+    int pb = mc_chroma(RCb, Wc, Hc, xp / 2, yp / 2, cxl, cyl, mvx[qc], mvy[qc]);
+    int pr = mc_chroma(RCr, Wc, Hc, xp / 2, yp / 2, cxl, cyl, mvx[qc], mvy[qc]);
+    if (iabs((int)Cb[co] - pb) <= MAXDIFF) Cb[co] = (uint8_t)pb;
+    if (iabs((int)Cr[co] - pr) <= MAXDIFF) Cr[co] = (uint8_t)pr;
+}
+
+void fer_launch_me_finish(const FerDev &d, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_me_finish, dim3(d.nmb, d.S), dim3(64), 0, st, d);
 }
 
 void fer_launch_me_pre(const FerDev &d, hipStream_t st)
@@ -666,19 +982,21 @@ void fer_launch_me_pre(const FerDev &d, hipStream_t st)
         hipLaunchKernelGGL(k_me_pre<0>, g, dim3(64), 0, st, d);
 }
 
-int fer_me_resolve_launches(const FerDev &d) { return 2 * d.mbw + 3 * (2 * d.mbh - 1); }
+int fer_me_resolve_launches(const FerDev &d)
+{
+    (void)d;
+    return 1;
+}
 
 void fer_launch_me_resolve(const FerDev &d, hipStream_t st)
 {
-    int gw = 2 * d.mbw, gh = 2 * d.mbh;
-    int ndiag = gw + 3 * (gh - 1);
-    int maxk = min(gh, (gw + 2) / 3);
-    for (int dg = 0; dg < ndiag; dg++) {
-        if (d.window == 32)
-            hipLaunchKernelGGL(k_me_resolve<32>, dim3(maxk, d.S), dim3(64), 0, st, d, dg);
-        else if (d.window == 16)
-            hipLaunchKernelGGL(k_me_resolve<16>, dim3(maxk, d.S), dim3(64), 0, st, d, dg);
-        else
-            hipLaunchKernelGGL(k_me_resolve<0>, dim3(maxk, d.S), dim3(64), 0, st, d, dg);
-    }
+    const int gh = 2 * d.mbh;
+    hipMemsetAsync(d.chain, 0, sizeof(int), st);
+    dim3 g(gh * d.S);
+    if (d.window == 32)
+        hipLaunchKernelGGL(k_me_resolve<32>, g, dim3(64), 0, st, d);
+    else if (d.window == 16)
+        hipLaunchKernelGGL(k_me_resolve<16>, g, dim3(64), 0, st, d);
+    else
+        hipLaunchKernelGGL(k_me_resolve<0>, g, dim3(64), 0, st, d);
 }

@@ -11,16 +11,30 @@ struct MvCtx {
     const short *mv;      // stream base [nmb][4][2]
     const int *mb_type;   // stream base, or nullptr when every macroblock is known to be inter (encoder)
     int mbw, cur, type;
+    bool coh;             // vectors are read while other wavefronts of the same launch publish them: agent-scope loads
 };
+
+// one quadrant's vector as a packed (x | y << 16) word; `coh` = coherent across the XCDs' L2s
+__device__ __forceinline__ int ld_mv(const short *mv, size_t q, bool coh)
+{
+    const int *p = (const int *)(mv + q * 2);
+    return coh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+__device__ __forceinline__ void st_mv_coh(short *mv, size_t q, int x, int y)
+{
+    __hip_atomic_store((int *)(mv + q * 2), (x & 0xffff) | (y << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ int p_part_w(int t) { return (t == 0 || t == 1 || t == FER_P_SKIP) ? 16 : 8; }
 __device__ __forceinline__ int p_part_h(int t) { return (t == 0 || t == 2 || t == FER_P_SKIP) ? 16 : 8; }
 
-// neighbour location + motion vector, F/mode_pred.cpp:49-110 (all MBs of a P picture are inter here)
-__device__ void nbr_fetch(const MvCtx &c, int xN, int yN, bool &valid, int &mx, int &my, int &ref)
+// neighbour location, F/mode_pred.cpp:60-110: macroblock and 8x8 quadrant holding sample (xN, yN)
+// relative to the current macroblock; valid = inside the picture and already decoded
+__device__ __forceinline__ void nbr_locate(int W, int cur, int xN, int yN, bool &valid, int &mbN, int &q)
 {
-    int W = c.mbw, cur = c.cur;
-    int xW = xN, yW = yN, mbN = cur;
+    int xW = xN, yW = yN;
+    mbN = cur;
+    q = 0;
     valid = false;
     if (xW > 15 && yW >= 0) return;
     if (yW > 15) return;
@@ -51,8 +65,16 @@ __device__ void nbr_fetch(const MvCtx &c, int xN, int yN, bool &valid, int &mx, 
             }
         }
     }
+    q = ((yW >> 3) << 1) + (xW >> 3);
+}
+
+// neighbour motion vector (all MBs of a P picture are inter in the encoder)
+__device__ void nbr_fetch(const MvCtx &c, int xN, int yN, bool &valid, int &mx, int &my, int &ref)
+{
+    int mbN, q;
+    nbr_locate(c.mbw, c.cur, xN, yN, valid, mbN, q);
     if (!valid) return;
-    if (c.mb_type && mbN != cur) {  // get_neighbour_mv (F/mode_pred.cpp:49-58): intra neighbour -> (0,0), refIdx -1
+    if (c.mb_type && mbN != c.cur) {  // get_neighbour_mv (F/mode_pred.cpp:49-58): intra neighbour -> (0,0), refIdx -1
         int t = c.mb_type[mbN];
         if (t >= 5 && t <= 30) {
             mx = 0;
@@ -61,13 +83,56 @@ __device__ void nbr_fetch(const MvCtx &c, int xN, int yN, bool &valid, int &mx, 
             return;
         }
     }
-    int q = ((yW >> 3) << 1) + (xW >> 3);
-    mx = c.mv[((size_t)mbN * 4 + q) * 2];
-    my = c.mv[((size_t)mbN * 4 + q) * 2 + 1];
+    int w = ld_mv(c.mv, (size_t)mbN * 4 + q, c.coh);
+    mx = (int)(short)(w & 0xffff);
+    my = w >> 16;
     ref = 0;
 }
 
 __device__ __forceinline__ int med3(int a, int b, int c) { return max(min(a, b), min(c, max(a, b))); }
+
+// median rule of PredictMV_Luma (F/mode_pred.cpp:322-371) once A, B, C (C already replaced by D when
+// unavailable) are known: mx == FER_MV_NA marks an unavailable neighbour, ref is 0 or -1
+__device__ __forceinline__ void predict_core(int mx[3], int my[3], int ref[3], int &ox, int &oy)
+{
+    if (mx[0] == FER_MV_NA && mx[1] == FER_MV_NA) {
+        mx[0] = 0;
+        my[0] = 0;
+        ref[0] = 0;
+    }
+    if (mx[0] == FER_MV_NA && mx[1] != FER_MV_NA) {
+        mx[0] = 0;
+        my[0] = 0;
+        ref[0] = -1;
+    }
+    if (mx[1] == FER_MV_NA) {
+        mx[1] = mx[0];
+        my[1] = my[0];
+        ref[1] = ref[0];
+    }
+    if (mx[2] == FER_MV_NA) {
+        mx[2] = mx[0];
+        my[2] = my[0];
+        ref[2] = ref[0];
+    }
+    if (ref[0] == 0 && ref[1] != 0 && ref[2] != 0) {
+        ox = mx[0];
+        oy = my[0];
+        return;
+    }
+    if (ref[0] != 0 && ref[1] == 0 && ref[2] != 0) {
+        ox = mx[1];
+        oy = my[1];
+        return;
+    }
+    if (ref[0] != 0 && ref[1] != 0 && ref[2] == 0) {
+        ox = mx[2];
+        oy = my[2];
+        return;
+    }
+    ox = med3(mx[0], mx[1], mx[2]);
+    oy = med3(my[0], my[1], my[2]);
+}
 
 // PredictMV_Luma, F/mode_pred.cpp:252-371, for reference index 0 everywhere
 __device__ void predict_luma(const MvCtx &c, int part, int &ox, int &oy)
@@ -113,42 +178,5 @@ __device__ void predict_luma(const MvCtx &c, int part, int &ox, int &oy)
         oy = my[2];
         return;
     }
-    if (mx[0] == FER_MV_NA && mx[1] == FER_MV_NA) {
-        mx[0] = 0;
-        my[0] = 0;
-        ref[0] = 0;
-    }
-    if (mx[0] == FER_MV_NA && mx[1] != FER_MV_NA) {
-        mx[0] = 0;
-        my[0] = 0;
-        ref[0] = -1;
-    }
-    if (mx[1] == FER_MV_NA) {
-        mx[1] = mx[0];
-        my[1] = my[0];
-        ref[1] = ref[0];
-    }
-    if (mx[2] == FER_MV_NA) {
-        mx[2] = mx[0];
-        my[2] = my[0];
-        ref[2] = ref[0];
-    }
-    if (ref[0] == 0 && ref[1] != 0 && ref[2] != 0) {
-        ox = mx[0];
-        oy = my[0];
-        return;
-    }
-    if (ref[0] != 0 && ref[1] == 0 && ref[2] != 0) {
-        ox = mx[1];
-        oy = my[1];
-        return;
-    }
-    if (ref[0] != 0 && ref[1] != 0 && ref[2] == 0) {
-        ox = mx[2];
-        oy = my[2];
-        return;
-    }
-    ox = med3(mx[0], mx[1], mx[2]);
-    oy = med3(my[0], my[1], my[2]);
+    predict_core(mx, my, ref, ox, oy);
 }
-

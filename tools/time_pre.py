@@ -13,4 +13,8 @@ g.fill_interpolated()
 g.profile(True)
 for _ in range(3):
     g.inter_encoding()
+if int(os.environ.get("FER_DBG", "0")) & 128:
+    t = g.read("TIMING")
+    print("probe row: us per partition: wait %.2f  decide %.2f  publish %.2f  (n=%d)" % (t[0] / t[3] / 100, t[1] / t[3] / 100, t[2] / t[3] / 100, t[3]))
+    print("  decide split: " + "  ".join("%s %.2f" % (n, t[4 + k] / t[3] / 100) for k, n in enumerate(["skiptest", "pred+m2+featissue", "select2", "select1", "sads", "best"])))
 print(os.environ.get("FER_DBG", "0"), {k: round(v[0] / 3, 2) for k, v in g.get_profile().items() if v[0] > 0})
