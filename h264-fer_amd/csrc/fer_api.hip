@@ -149,9 +149,13 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     rc |= dalloc(c, &d.feat, d.ysz * 96 * S);
     rc |= dalloc(c, &d.feat0, d.ysz * 6 * S);
     rc |= dalloc(c, &d.sort_pos, d.ysz * S);
-    rc |= dalloc(c, &d.sort_rec, d.ysz * S);
-    rc |= dalloc(c, &d.sort_k34, d.ysz * S);
-    rc |= dalloc(c, &d.koliko, (size_t)16385 * S);
+    rc |= dalloc(c, &d.sort_rec, d.ysz * S * 3);
+    d.ktw_shift = 3;  // column tiles of the bucket index: at most 64 per row, at least 8 columns wide
+    while (((W + (1 << d.ktw_shift) - 1) >> d.ktw_shift) > 64) d.ktw_shift++;
+    d.kt = (W + (1 << d.ktw_shift) - 1) >> d.ktw_shift;
+    const size_t nbins = (size_t)S * 16384 * d.kt + 1;
+    rc |= dalloc(c, &d.kol2, nbins);
+    rc |= dalloc(c, &d.kol2_hist, nbins);
     size_t nm = (size_t)d.nmb * S;
     rc |= dalloc(c, &d.mb_type, nm);
     rc |= dalloc(c, &d.mv, nm * 8);
@@ -187,7 +191,12 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     rc |= dalloc(c, &c->sort.keys_out, (size_t)n * S);
     rc |= dalloc(c, &c->sort.vals_in, (size_t)n * S);
     rc |= dalloc(c, &c->sort.vals_out, (size_t)n * S);
-    rc |= dalloc(c, &c->sort.seg_begin, (size_t)S + 1);
+    c->sort.scan_tmp_bytes = fer_scan_tmp_bytes(nbins);
+    {
+        uint8_t *stmp = nullptr;
+        rc |= dalloc(c, &stmp, c->sort.scan_tmp_bytes);
+        c->sort.scan_tmp = stmp;
+    }
     uint8_t *tmp = nullptr;
     rc |= dalloc(c, &tmp, c->sort.tmp_bytes);
     c->sort.tmp = tmp;
@@ -199,11 +208,6 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     CK(hipHostMalloc((void **)&c->h_len, sizeof(uint32_t) * S));
     CK(hipHostMalloc((void **)&c->h_status, sizeof(int) * S));
     CK(hipHostMalloc((void **)&c->h_sad, sizeof(unsigned long long) * S));
-    {
-        std::vector<unsigned> seg(S + 1);
-        for (int i = 0; i <= S; i++) seg[i] = (unsigned)((size_t)i * n);
-        CK(hipMemcpy(c->sort.seg_begin, seg.data(), sizeof(unsigned) * (S + 1), hipMemcpyHostToDevice));
-    }
     c->ss.assign(S, StreamState{0, 0, 0, 0, 0, 0});
     c->types.assign(S, 2);
     c->cur_set = 0;
@@ -752,7 +756,18 @@ extern "C" size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t
     case FERHIP_BUF_INTERP: src = d.interp; n = d.ysz * 16 * d.S; break;
     case FERHIP_BUF_FEAT: src = d.feat; n = d.ysz * 96 * d.S * 2; break;
     case FERHIP_BUF_SORTPOS: src = d.sort_pos; n = d.ysz * d.S * 4; break;
-    case FERHIP_BUF_KOLIKO: src = d.koliko; n = (size_t)16385 * d.S * 4; break;
+    case FERHIP_BUF_KOLIKO: {  // the reference's koliko[] = first level of the bucket index, relative to the stream's segment
+        n = (size_t)16385 * d.S * 4;
+        if (n > cap) return 0;
+        if (hipStreamSynchronize(c->st) != hipSuccess) return 0;
+        for (int s = 0; s < d.S; s++) {
+            int *o = (int *)dst + (size_t)s * 16385;
+            if (hipMemcpy2D(o, 4, d.kol2 + (size_t)s * 16384 * d.kt, (size_t)d.kt * 4, 4, 16385, hipMemcpyDeviceToHost) != hipSuccess)
+                return 0;
+            for (int a = 0; a <= 16384; a++) o[a] -= (int)((size_t)s * d.ysz);
+        }
+        return n;
+    }
     case FERHIP_BUF_MBTYPE: src = d.mb_type; n = nm * 4; break;
     case FERHIP_BUF_MV: src = d.mv; n = nm * 16; break;
     case FERHIP_BUF_MVD: src = d.mvd; n = nm * 16; break;

@@ -36,9 +36,13 @@ struct FerDev {
     uint16_t *feat;      // [S][H][W][16][6]  k0..k4 + pad per (position, frac): one 12-byte load per candidate
     uint16_t *feat0;     // [S][H][W][6]      plane-0 copy for the wide integer search
     uint32_t *sort_pos;  // [S][W*H]  (tx << 16) | ty, ordered by (sum, tx, ty)
-    uint2 *sort_rec;     // [S][W*H]  {.x = (tx << 16) | ty, .y = kar1 | kar2 << 16}: what the bucket walk filters on
-    uint32_t *sort_k34;  // [S][W*H]  kar3 | kar4 << 16 of that position
-    int *koliko;         // [S][16385] bucket start offsets
+    uint32_t *sort_rec;  // [S*W*H][3] {(tx << 16) | ty, kar1 | kar2 << 16, kar3 | kar4 << 16}: what the bucket walk reads
+    // Two-level bucket index over the device-wide sorted order (stream-major): kol2[(s*16384 + a)*kt + t] = index of
+    // the first sorted record of stream s with sum a and tx >= t << ktw_shift (a tile of columns); the entry at
+    // t == kt is the next bucket's first.  koliko[a] of the reference = kol2[(s*16384 + a)*kt] - s*W*H.
+    uint32_t *kol2;      // [S*16384*kt + 1]
+    uint32_t *kol2_hist; // same size: (sum, column tile) histogram the index is the exclusive scan of
+    int kt, ktw_shift;
     // per-MB side information (a20)
     int *mb_type;        // [S][nmb]
     int *prev_mb_type;   // [S][nmb] mb_type_array left by the previous picture

@@ -199,25 +199,65 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
     __syncthreads();
 }
 
-// the 9-term feature distance of F/moestimation.cpp:267-276 from one 12-byte feature record
-__device__ __forceinline__ int feat_dist_w(uint32_t a, uint32_t b, uint32_t c, const int s[5])
+// ---- the 9-term feature distance of F/moestimation.cpp:267-276 on packed 16-bit pairs ----
+// A 12-byte record holds (k0,k1) (k2,k3) (k4,0) as u16 pairs, k0 = sum of the 8x8 box and k1..k4 = sums of half
+// of its samples, so every k0 - ki is >= 0 and everything fits unsigned 16 bit.  With the source
+// sums arranged the same way the nine terms are six v_sad_u16:
+//   |s0-k0| + |s1-k1|, |s2-k2| + |s3-k3|, |s4-k4|, and |(s0-si) - (k0-ki)| for i = 1..4.
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b)
 {
-    int k0 = (int)(a & 0xffff), k1 = (int)(a >> 16), k2 = (int)(b & 0xffff), k3 = (int)(b >> 16), k4 = (int)(c & 0xffff);
-    return iabs(s[0] - k0) + iabs(s[1] - k1) + iabs(s[0] - s[1] - k0 + k1) + iabs(s[2] - k2) +
-           iabs(s[0] - s[2] - k0 + k2) + iabs(s[3] - k3) + iabs(s[0] - s[3] - k0 + k3) + iabs(s[4] - k4) +
-           iabs(s[0] - s[4] - k0 + k4);
+    return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) - __builtin_bit_cast(u16x2_t, b)));
 }
-__device__ __forceinline__ int feat_dist_rec(const uint16_t *__restrict__ rec, const int s[5])
+__device__ __forceinline__ uint32_t pk_abs16(uint32_t a)
+{
+    i16x2_t x = __builtin_bit_cast(i16x2_t, a), z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(x, (i16x2_t)(z - x)));
+}
+struct SuPk {  // source sums of one partition, wave-uniform
+    uint32_t s01, s23, s4;  // (s0,s1) (s2,s3) (s4,0)
+    uint32_t d01, d23, d4;  // (0,s0-s1) (s0-s2,s0-s3) (s0-s4,0)
+    uint32_t s12, s34;      // (s1,s2) (s3,s4): the pairing of the sorted records
+    uint32_t e12, e34;      // (s0-s1,s0-s2) (s0-s3,s0-s4)
+};
+__device__ __forceinline__ SuPk su_pack(const int s[5])
+{
+    SuPk p;
+    p.s01 = (uint32_t)s[0] | ((uint32_t)s[1] << 16);
+    p.s23 = (uint32_t)s[2] | ((uint32_t)s[3] << 16);
+    p.s4 = (uint32_t)s[4];
+    p.d01 = (uint32_t)(s[0] - s[1]) << 16;
+    p.d23 = (uint32_t)(s[0] - s[2]) | ((uint32_t)(s[0] - s[3]) << 16);
+    p.d4 = (uint32_t)(s[0] - s[4]);
+    p.s12 = (uint32_t)s[1] | ((uint32_t)s[2] << 16);
+    p.s34 = (uint32_t)s[3] | ((uint32_t)s[4] << 16);
+    p.e12 = (uint32_t)(s[0] - s[1]) | ((uint32_t)(s[0] - s[2]) << 16);
+    p.e34 = (uint32_t)(s[0] - s[3]) | ((uint32_t)(s[0] - s[4]) << 16);
+    return p;
+}
+__device__ __forceinline__ int feat_dist_w(uint32_t a, uint32_t b, uint32_t c, const SuPk &p)
+{
+    uint32_t t = __builtin_amdgcn_sad_u16(a, p.s01, 0);
+    t = __builtin_amdgcn_sad_u16(b, p.s23, t);
+    t = __builtin_amdgcn_sad_u16(c, p.s4, t);
+    uint32_t kk = __builtin_amdgcn_perm(a, a, 0x01000100);  // (k0,k0)
+    t = __builtin_amdgcn_sad_u16(pk_sub16(kk, a), p.d01, t);
+    t = __builtin_amdgcn_sad_u16(pk_sub16(kk, b), p.d23, t);
+    t = __builtin_amdgcn_sad_u16(pk_sub16(kk, c) & 0xffffu, p.d4, t);
+    return (int)t;
+}
+__device__ __forceinline__ int feat_dist_rec(const uint16_t *__restrict__ rec, const SuPk &p)
 {
     const uint32_t *r = (const uint32_t *)rec;
-    return feat_dist_w(r[0], r[1], r[2], s);
+    return feat_dist_w(r[0], r[1], r[2], p);
 }
 // ... at (frac, refy, refx) of the all-fracs array
 __device__ __forceinline__ int feat_dist(const uint16_t *__restrict__ Fs, size_t ysz, int W, int frac, int refy,
-                                         int refx, const int s[5])
+                                         int refx, const SuPk &p)
 {
     (void)ysz;
-    return feat_dist_rec(Fs + (((size_t)refy * W + refx) * 16 + frac) * 6, s);
+    return feat_dist_rec(Fs + (((size_t)refy * W + refx) * 16 + frac) * 6, p);
 }
 // Record fetch without control flow: coordinates are clamped into the picture so that the load
 // can always be issued (the caller masks candidates outside the picture afterwards).  Loads
@@ -230,6 +270,17 @@ __device__ __forceinline__ FeatRec feat_load(const uint16_t *__restrict__ Fs, in
 {
     int y = iclamp(refy, 0, H - 1), x = iclamp(refx, 0, W - 1);
     const uint32_t *r = (const uint32_t *)(Fs + (((size_t)y * W + x) * 16 + frac) * 6);
+    FeatRec f;
+    f.a = r[0];
+    f.b = r[1];
+    f.c = r[2];
+    return f;
+}
+// ... from the plane-0 copy [H][W][6]
+__device__ __forceinline__ FeatRec feat0_load(const uint16_t *__restrict__ F0, int W, int H, int refy, int refx)
+{
+    int y = iclamp(refy, 0, H - 1), x = iclamp(refx, 0, W - 1);
+    const uint32_t *r = (const uint32_t *)(F0 + ((size_t)y * W + x) * 6);
     FeatRec f;
     f.a = r[0];
     f.b = r[1];
@@ -317,6 +368,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     su[3] = wave_sum((py & 3) > 1 ? 0 : v);
     su[4] = wave_sum((px & 3) > 1 ? 0 : v);
     if (lane < 5) d.suma[pidx * 5 + lane] = su[lane];
+    const SuPk sp = su_pack(su);
 
     // source rows for the SAD groups (sx is a multiple of 8: aligned dwords)
     const int row = lane & 7;
@@ -333,20 +385,37 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     const int wb = (n * n + 63) >> 6;  // batches of the wide search
     if (n * n <= ME_WIDE_LDS && wb + ((nloc + 63) >> 6) <= ME_SEL_NB && !(d.dbg & 3)) {
         // pass A: lanes run along x (contiguous 12-byte records); metrics land in LDS at their
-        // arrival index (tx outer, ty inner).
-        for (int base = 0; base < n * n; base += 64) {
-            int c = base + lane;
-            if (c < n * n) {
-                int iy = c / n, ix = c % n;
+        // arrival index (tx outer, ty inner).  Records are fetched six batches at a time with
+        // clamped coordinates (no control flow around the loads), then masked.
+        constexpr int WCH = 6;
+        for (int base = 0; base < n * n; base += 64 * WCH) {
+            FeatRec fr[WCH];
+#pragma unroll
+            for (int q = 0; q < WCH; q++) {
+                int c = min(base + q * 64 + lane, n * n - 1);
+                fr[q] = feat0_load(F0, W, H, sy + c / n - R, sx + c % n - R);
+            }
+#pragma unroll
+            for (int q = 0; q < WCH; q++) {
+                int c = base + q * 64 + lane;
+                int cc = min(c, n * n - 1);
+                int iy = cc / n, ix = cc % n;
                 int tx = ix - R, ty = iy - R;
                 int rx = sx + tx, ry = sy + ty;
-                int m = -1;
-                if (rx >= 0 && rx < W && ry >= 0 && ry < H)
-                    m = (iabs(tx) + iabs(ty) + 4) * feat_dist_rec(F0 + ((size_t)ry * W + rx) * 6, su);
-                wide_m[ix * n + iy] = m;
+                int m = (iabs(tx) + iabs(ty) + 4) * feat_dist_w(fr[q].a, fr[q].b, fr[q].c, sp);
+                if (!(rx >= 0 && rx < W && ry >= 0 && ry < H)) m = -1;
+                if (c < n * n) wide_m[ix * n + iy] = m;
             }
         }
         __syncthreads();
+        constexpr int LB = 7;  // batches of the local search that ME_SEL_NB leaves room for
+        FeatRec fl[LB];
+#pragma unroll
+        for (int q = 0; q < LB; q++) {
+            int c = q * 64 + lane;
+            int frac = c & 15, pos = c >> 4;
+            fl[q] = feat_load(Fs, W, H, frac, sy + pos % n2w - r2, sx + pos / n2w - r2);
+        }
         int v[ME_SEL_NB];
 #pragma unroll
         for (int u = 0; u < ME_SEL_NB; u++) {
@@ -354,13 +423,14 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
             if (u < wb) {
                 int c = u * 64 + lane;
                 if (c < n * n) v[u] = wide_m[c];
-            } else {
+            } else if (u - wb < LB) {
                 int c = (u - wb) * 64 + lane;
-                int frac = c & 15, pos = c >> 4;
+                int pos = c >> 4;
                 int tx = pos / n2w - r2, ty = pos % n2w - r2;
                 int rx = sx + tx, ry = sy + ty;
-                if (c < nloc && rx >= 0 && rx < W && ry >= 0 && ry < H)
-                    v[u] = (iabs(tx) + iabs(ty) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, su);
+                int m = (iabs(tx) + iabs(ty) + 4) * feat_dist_w(fl[u - wb < LB ? u - wb : 0].a, fl[u - wb < LB ? u - wb : 0].b,
+                                                                 fl[u - wb < LB ? u - wb : 0].c, sp);
+                if (c < nloc && rx >= 0 && rx < W && ry >= 0 && ry < H) v[u] = m;
             }
         }
         auto pay = [&](int u) {  // vector of the lane's candidate u
@@ -380,7 +450,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
             int rx = sx + tx, ry = sy + ty;
             bool ok = c < n * n && rx >= 0 && rx < W && ry >= 0 && ry < H;
             int m = 0;
-            if (ok) m = (iabs(tx) + iabs(ty) + 4) * feat_dist_rec(F0 + ((size_t)ry * W + rx) * 6, su);
+            if (ok) m = (iabs(tx) + iabs(ty) + 4) * feat_dist_rec(F0 + ((size_t)ry * W + rx) * 6, sp);
             wl_insert(L, 33, lane, ok, m, pack_xy(tx * 4, ty * 4));
         }
         for (int base = 0; base < nloc && !(d.dbg & 2); base += 64) {
@@ -390,90 +460,164 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
             int rx = sx + tx, ry = sy + ty;
             bool ok = c < nloc && rx >= 0 && rx < W && ry >= 0 && ry < H;
             int m = 0;
-            if (ok) m = (iabs(tx) + iabs(ty) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, su);
+            if (ok) m = (iabs(tx) + iabs(ty) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, sp);
             wl_insert(L, 33, lane, ok, m, pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2)));
         }
     }
-    int n3 = __popcll(__ballot(lane < 33 && L.m < 100000000));
-    for (int base = 0; base < n3 && !(d.dbg & 4); base += 8) {
-        int j = base + (lane >> 3);
-        int xy = __shfl(L.xy, j < 33 ? j : 0);
-        int bx = unp_x(xy), by = unp_y(xy);
-        int sad = sad8_rows(Ps, ysz, W, H, sx, sy, bx, by, row, src0, src1);
-        if (j < n3 && row == 0) {
-            int *o = d.st3 + (pidx * 33 + j) * 3;
-            o[0] = bx;
-            o[1] = by;
-            o[2] = sad;
+    const int n3 = __popcll(__ballot(lane < 33 && L.m < 100000000));
+    if (!(d.dbg & 4)) {  // SADs of the survivors: all five rounds' rows requested before the first reduction
+        SadRow rr[5];
+        int xyr[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            int j = r * 8 + (lane >> 3);
+            xyr[r] = __shfl(L.xy, j < 33 ? j : 0);
+            rr[r] = sad_row_load(Ps, ysz, W, H, sx, sy, unp_x(xyr[r]), unp_y(xyr[r]), row);
+        }
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            int j = r * 8 + (lane >> 3);
+            int sad = sad_row_reduce(rr[r], src0, src1);
+            if (j < n3 && row == 0) {
+                int *o = d.st3 + (pidx * 33 + j) * 3;
+                o[0] = unp_x(xyr[r]);
+                o[1] = unp_y(xyr[r]);
+                o[2] = sad;
+            }
         }
     }
     if (lane == 0) d.st3n[pidx] = n3;
 
-    // ---- stage 2 candidate set: bucket walk of F/moestimation.cpp:470-496 (weight applied later)
-    const int *kol = d.koliko + (size_t)s * 16385;
-    const uint2 *srec = d.sort_rec + (size_t)s * ysz;
-    const uint32_t *sk34 = d.sort_k34 + (size_t)s * ysz;
+}
+
+// ------------------------------------------------------------------ k_me_walk
+// Stage-2 candidate set of every 8x8 partition: the bucket walk of F/moestimation.cpp:470-496 (the
+// predictor weight is applied later, in k_me_resolve).  Kept apart from k_me_pre because it is a
+// latency-bound stream of 12-byte records that wants many resident wavefronts and few registers.
+__global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
+{
+    const int lane = threadIdx.x;
+    const int s = blockIdx.y;
+    if (d.hdr[s * 4 + 3] != 0) return;
+    const int mb = blockIdx.x >> 2, part = blockIdx.x & 3;
+    const int W = d.W;
+    const uint8_t *Y = d.curY + (size_t)s * d.ysz;
+    const int sx = ((mb % d.mbw) << 4) + (part & 1) * 8, sy = ((mb / d.mbw) << 4) + (part >> 1) * 8;
+    const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
+    // box sums of the source block, F/moestimation.cpp:440-451 (k_me_pre derives and stores the same)
+    int px = lane & 7, py = lane >> 3;
+    int v = Y[(size_t)(sy + py) * W + sx + px];
+    int su[5];
+    su[0] = wave_sum(v);
+    su[1] = wave_sum(py > 3 ? 0 : v);
+    su[2] = wave_sum(px > 3 ? 0 : v);
+    su[3] = wave_sum((py & 3) > 1 ? 0 : v);
+    su[4] = wave_sum((px & 3) > 1 ? 0 : v);
+    const SuPk sp = su_pack(su);
+
+    // For j = 0, 1, ... the buckets su[0]-j and su[0]+j are scanned in (tx, ty) order; a candidate passes when it is
+    // inside the 280-diamond and its two half sums are within 100; the walk stops after the j that takes the count
+    // past 128.  Buckets are entered through the column-tile index, so only the slice whose tx can pass is read,
+    // and the slices are cut into 64-entry batches that are fetched two ahead of the one being filtered (each
+    // record is one 12-byte load; the exact filter decides, so the candidate set and its order are the reference's).
     int tren = 0;
     if (!d.basic && !(d.dbg & 8)) {
-        int kl0 = 0, kl1 = 0, kh0 = 0, kh1 = 0;
-        for (int j = 0; j <= 180; j++) {
-            if ((j & 63) == 0) {  // bucket bounds of the next 64 steps on both sides, one lane per step
-                int al = su[0] - (j + lane), ah = su[0] + (j + lane);
-                bool vl = al >= 0 && al < 16384, vh = ah >= 0 && ah < 16384;
-                kl0 = vl ? kol[al] : 0;
-                kl1 = vl ? kol[al + 1] : 0;
-                kh0 = vh ? kol[ah] : 0;
-                kh1 = vh ? kol[ah + 1] : 0;
+        const int kt = d.kt;
+        const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * kt;
+        const uint32_t *srec = d.sort_rec;  // indexed by the device-wide positions kol2 holds
+        const int t_lo = max(sx - 279, 0) >> d.ktw_shift, t_hi = min(sx + 279, W - 1) >> d.ktw_shift;
+        const unsigned long long ltm = (1ull << lane) - 1ull;
+        // slice generator state (wave-uniform): bounds of 64 steps j on both sides live one per lane
+        int jn = 0, side = 0;             // next slice to open
+        unsigned cur = 0, end = 0;        // rest of the open slice
+        int cur_a = 0, cur_last = 0;      // its bucket; 1 = second side of its j (the stop test follows it)
+        unsigned kl0 = 0, kl1 = 0, kh0 = 0, kh1 = 0;
+        bool open = false, done = false;
+        // next batch: start index, entry count (0 = nothing to read), bucket, flags (1 = stop test after it, 2 = end of walk)
+        auto gen = [&](unsigned &b_start, int &b_cnt, int &b_a, int &b_flags) {
+            b_start = 0;
+            b_cnt = 0;
+            b_a = 0;
+            b_flags = 0;
+            if (done) {
+                b_flags = 2;
+                return;
             }
-            for (int side = 0; side < 2; side++) {
-                int a = side ? su[0] + j : su[0] - j;
-                if (a < 0 || a >= 16384) continue;
-                int k0 = lane_bcast(side ? kh0 : kl0, j & 63), k1 = lane_bcast(side ? kh1 : kl1, j & 63);
-                // A bucket is ordered by (tx, ty) and the filter needs |tx - sx| < 280: probe 64
-                // evenly spaced entries once and walk only the slice whose tx can pass (the exact
-                // filter below still decides, so the candidate set and its order are unchanged).
-                if (k1 - k0 > 128) {
-                    int len = k1 - k0;
-                    int pk = k0 + (int)(((long long)len * lane) >> 6);
-                    int ptx = (int)(srec[pk].x >> 16);
-                    int nlo = __popcll(__ballot(ptx <= sx - 280));  // probes certainly left of the window
-                    int nhi = __popcll(__ballot(ptx < sx + 280));   // probes not yet right of it
-                    int s0 = nlo > 0 ? k0 + (int)(((long long)len * (nlo - 1)) >> 6) : k0;
-                    int s1 = nhi < 64 ? k0 + (int)(((long long)len * nhi) >> 6) : k1;
-                    k0 = s0;
-                    k1 = s1;
+            if (!open) {
+                if (jn > 180) {
+                    done = true;
+                    b_flags = 2;
+                    return;
                 }
-                for (int base = k0; base < k1; base += 64) {
-                    int k = base + lane;
-                    bool ok = false;
-                    int tx = 0, ty = 0, q1 = 0, q2 = 0;
-                    if (k < k1) {
-                        uint2 e = srec[k];
-                        int ax = (int)(e.x >> 16), ay = (int)(e.x & 0xffff);
-                        q1 = (int)(e.y & 0xffff);
-                        q2 = (int)(e.y >> 16);
-                        tx = ax - sx;
-                        ty = ay - sy;
-                        ok = iabs(tx) + iabs(ty) < 280 && iabs(q1 - su[1]) < 100 && iabs(q2 - su[2]) < 100;
-                    }
-                    unsigned long long mk = __ballot(ok);
-                    if (mk) {
-                        int rank = tren + __popcll(mk & ((1ull << lane) - 1));
-                        if (ok && rank < FER_ST2_CAP) {  // feature distance from the sorted payload: k0 == a, no scattered reads
-                            uint32_t r = sk34[k];
-                            int q3 = (int)(r & 0xffff), q4 = (int)(r >> 16);
-                            int D = iabs(su[0] - a) + iabs(su[1] - q1) + iabs(su[0] - su[1] - a + q1) + iabs(su[2] - q2) +
-                                    iabs(su[0] - su[2] - a + q2) + iabs(su[3] - q3) + iabs(su[0] - su[3] - a + q3) +
-                                    iabs(su[4] - q4) + iabs(su[0] - su[4] - a + q4);
-                            int *o = d.st2 + (pidx * FER_ST2_CAP + rank) * 2;
-                            o[0] = pack_xy(tx, ty);
-                            o[1] = D;
-                        }
-                        tren += __popcll(mk);
-                    }
+                if (side == 0 && (jn & 63) == 0) {  // bucket bounds of the next 64 steps, one step per lane
+                    int al = su[0] - (jn + lane), ah = su[0] + (jn + lane);
+                    bool vl = al >= 0 && al < 16384, vh = ah >= 0 && ah < 16384;
+                    kl0 = vl ? kol2[(size_t)al * kt + t_lo] : 0u;
+                    kl1 = vl ? kol2[(size_t)al * kt + t_hi + 1] : 0u;
+                    kh0 = vh ? kol2[(size_t)ah * kt + t_lo] : 0u;
+                    kh1 = vh ? kol2[(size_t)ah * kt + t_hi + 1] : 0u;
                 }
+                cur = (unsigned)lane_bcast((int)(side ? kh0 : kl0), jn & 63);
+                end = (unsigned)lane_bcast((int)(side ? kh1 : kl1), jn & 63);
+                cur_a = side ? su[0] + jn : su[0] - jn;
+                cur_last = side;
+                open = true;
+                if (side) jn++;
+                side ^= 1;
             }
-            if (tren > 128) break;
+            b_start = cur;
+            b_cnt = end > cur ? (int)min(end - cur, 64u) : 0;
+            b_a = cur_a;
+            cur += 64;
+            if (cur >= end) {
+                open = false;
+                b_flags = cur_last;
+            }
+        };
+        auto fetch = [&](unsigned b_start, int b_cnt, uint32_t &r0, uint32_t &r1, uint32_t &r2) {
+            const uint32_t *e = srec + (size_t)(b_start + (unsigned)min(lane, max(b_cnt - 1, 0))) * 3;
+            r0 = e[0];
+            r1 = e[1];
+            r2 = e[2];
+        };
+        const uint32_t sxy = ((uint32_t)sx << 16) | (uint32_t)sy;  // the records' (tx << 16) | ty pairing
+        auto filter = [&](int b_cnt, int a, uint32_t r0, uint32_t r1, uint32_t r2) {
+            // |tx - sx| + |ty - sy| < 280 and both half sums within 100, on u16 pairs
+            uint32_t dist = __builtin_amdgcn_sad_u16(r0, sxy, 0);
+            uint32_t e12 = pk_abs16(pk_sub16(r1, sp.s12));
+            bool ok = lane < b_cnt && dist < 280u && (pk_sub16(e12, 0x00640064u) & 0x80008000u) == 0x80008000u;
+            unsigned long long mk = __ballot(ok);
+            int rank = tren + __popcll(mk & ltm);
+            // feature distance from the sorted payload (kar0 == a): |s0-a| + sum |si-qi| + sum |(s0-si) - (a-qi)|
+            uint32_t aa = (uint32_t)a | ((uint32_t)a << 16);
+            uint32_t D = __builtin_amdgcn_sad_u16(r1, sp.s12, (uint32_t)iabs(su[0] - a));
+            D = __builtin_amdgcn_sad_u16(r2, sp.s34, D);
+            D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r1), sp.e12, D);
+            D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r2), sp.e34, D);
+            if (ok && rank < FER_ST2_CAP) {
+                int2 *o = (int2 *)(d.st2 + (pidx * FER_ST2_CAP + rank) * 2);
+                *o = make_int2((int)pk_sub16(r0, sxy), (int)D);  // (tx - sx) << 16 | (ty - sy) & 0xffff
+            }
+            tren += __popcll(mk);
+        };
+        unsigned sA, sB;
+        int cA, cB, aA, aB, fA, fB;
+        uint32_t A0, A1, A2, B0, B1, B2;
+        gen(sA, cA, aA, fA);
+        fetch(sA, cA, A0, A1, A2);
+        gen(sB, cB, aB, fB);
+        fetch(sB, cB, B0, B1, B2);
+        for (;;) {  // two batches in flight, no register copies between them
+            if (fA & 2) break;
+            filter(cA, aA, A0, A1, A2);
+            if ((fA & 1) && tren > 128) break;
+            gen(sA, cA, aA, fA);
+            fetch(sA, cA, A0, A1, A2);
+            if (fB & 2) break;
+            filter(cB, aB, B0, B1, B2);
+            if ((fB & 1) && tren > 128) break;
+            gen(sB, cB, aB, fB);
+            fetch(sB, cB, B0, B1, B2);
         }
     }
     if (lane == 0) {
@@ -676,6 +820,7 @@ __device__ __forceinline__ int resolve_part(const FerDev &d, int s, int gx, int 
 
     RP_MARK(0)
     // ---- search of this 8x8 partition as part of a P_8x8ref0 macroblock
+    const SuPk sp = su_pack(P.su);
     int mvpx, mvpy;
     predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
     const int genx = mvpx >> 2, geny = mvpy >> 2;
@@ -692,10 +837,10 @@ __device__ __forceinline__ int resolve_part(const FerDev &d, int s, int gx, int 
 #pragma unroll
     for (int u = 0; u < FER_ST2_CAP / 64; u++) {
         int cc = u * 64 + lane;
-        int tx = unp_x(P.e2[u].x), ty = unp_y(P.e2[u].x);
+        int tx = P.e2[u].x >> 16, ty = (int)(short)(P.e2[u].x & 0xffff);  // k_me_pre stores (tx << 16) | (ty & 0xffff)
         m2[u] = (st2on && cc < P.n2) ? (iabs(tx - genx) + iabs(ty - geny) + 4) * P.e2[u].y : -1;
     }
-    auto pay2 = [&](int u) { return pack_xy(unp_x(P.e2[u].x) * 4, unp_y(P.e2[u].x) * 4); };
+    auto pay2 = [&](int u) { return pack_xy((P.e2[u].x >> 16) * 4, (int)(short)(P.e2[u].x & 0xffff) * 4); };
     auto pay1 = [&](int u) {
         int cc = u * 64 + lane;
         int frac = cc & 15, pos = cc >> 4;
@@ -717,7 +862,7 @@ __device__ __forceinline__ int resolve_part(const FerDev &d, int s, int gx, int 
             int tx = genx - r1 + pos / n1, ty = geny - r1 + pos % n1;
             int rx = sx + tx, ry = sy + ty;
             bool ok = cc < tot1 && rx >= 0 && rx < W && ry >= 0 && ry < H;
-            int mm = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist_w(fr[u].a, fr[u].b, fr[u].c, P.su);
+            int mm = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist_w(fr[u].a, fr[u].b, fr[u].c, sp);
             m[u] = ok ? mm : -1;
         }
         RP_MARK(1)
@@ -734,7 +879,7 @@ __device__ __forceinline__ int resolve_part(const FerDev &d, int s, int gx, int 
             int rx = sx + tx, ry = sy + ty;
             bool ok = cc < tot1 && rx >= 0 && rx < W && ry >= 0 && ry < H;
             int m = 0;
-            if (ok) m = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, P.su);
+            if (ok) m = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, sp);
             wl_insert(L1, 17, lane, ok, m, pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2)));
         }
         select_topk<FER_ST2_CAP / 64>(m2, 33, lane, sel_lds, L2, pay2);
@@ -980,6 +1125,7 @@ void fer_launch_me_pre(const FerDev &d, hipStream_t st)
         hipLaunchKernelGGL(k_me_pre<16>, g, dim3(64), 0, st, d);
     else
         hipLaunchKernelGGL(k_me_pre<0>, g, dim3(64), 0, st, d);
+    hipLaunchKernelGGL(k_me_walk, g, dim3(64), 0, st, d);
 }
 
 int fer_me_resolve_launches(const FerDev &d)

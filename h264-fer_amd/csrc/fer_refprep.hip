@@ -148,53 +148,45 @@ __global__ __launch_bounds__(256) void k_features(FerDev d)
 }
 
 // ------------------------------------------------------------------ sort by 8x8 sum
-// keys in arrival order b = tx*H + ty (the reference scans columns, F/moestimation.cpp:142-151)
+// keys in arrival order b = tx*H + ty (the reference scans columns, F/moestimation.cpp:142-151);
+// the same pass counts the positions per (sum, column tile) for the two-level bucket index
 __global__ void k_sort_keys(FerDev d, uint32_t *keys, uint32_t *vals)
 {
     const int s = blockIdx.y;
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     int n = d.W * d.H;
     if (b >= n) return;
-    if (d.hdr[s * 4 + 3] != 0) {  // not a P picture: keep the segment populated so the device-wide sort stays aligned
+    uint32_t *hist = d.kol2_hist + (size_t)s * 16384 * d.kt;
+    if (d.hdr[s * 4 + 3] != 0) {  // not a P picture: keep the segment populated so the device-wide order stays aligned
         keys[(size_t)s * n + b] = (uint32_t)s << 15;
         vals[(size_t)s * n + b] = 0;
+        if ((b & 63) == 0) atomicAdd(hist, (uint32_t)min(64, n - b));
         return;
     }
     int tx = b / d.H, ty = b % d.H;
     uint16_t k = d.feat0[((size_t)s * d.ysz + (size_t)ty * d.W + tx) * 6];
     keys[(size_t)s * n + b] = ((uint32_t)s << 15) | k;  // one device-wide sort: stream id above the 15-bit sum
     vals[(size_t)s * n + b] = ((uint32_t)tx << 16) | (uint32_t)ty;
+    atomicAdd(hist + (size_t)k * d.kt + (tx >> d.ktw_shift), 1u);
     if (k == 0) atomicOr(&d.status[s], FER_ERR_ZERO_SUM);  // the reference mis-files sum 0 (F/moestimation.cpp:153)
 }
 
-__global__ void k_sort_finish(FerDev d, const uint32_t *skeys, const uint32_t *svals)
+__global__ void k_sort_finish(FerDev d, const uint32_t *svals)
 {
     const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int n = d.W * d.H;
-    skeys += (size_t)s * n;
-    svals += (size_t)s * n;
-    if (i < n) {
-        uint32_t v = svals[i];
-        int tx = v >> 16, ty = v & 0xffff;
-        const uint32_t *r = (const uint32_t *)(d.feat0 + ((size_t)s * d.ysz + (size_t)ty * d.W + tx) * 6);
-        uint32_t a = r[0], b = r[1], c = r[2];  // k0|k1<<16, k2|k3<<16, k4
-        d.sort_pos[(size_t)s * n + i] = v;
-        d.sort_rec[(size_t)s * n + i] = make_uint2(v, (a >> 16) | (b << 16));
-        d.sort_k34[(size_t)s * n + i] = (b >> 16) | (c << 16);
-    }
-    if (i <= 16384) {  // koliko[a] = number of positions with sum < a
-        int lo = 0, hi = n;
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if ((skeys[mid] & 0x7fff) < (uint32_t)i)
-                lo = mid + 1;
-            else
-                hi = mid;
-        }
-        d.koliko[(size_t)s * 16385 + i] = lo;
-    }
+    if (i >= n) return;
+    uint32_t v = svals[(size_t)s * n + i];
+    int tx = v >> 16, ty = v & 0xffff;
+    const uint32_t *r = (const uint32_t *)(d.feat0 + ((size_t)s * d.ysz + (size_t)ty * d.W + tx) * 6);
+    uint32_t a = r[0], b = r[1], c = r[2];  // k0|k1<<16, k2|k3<<16, k4
+    d.sort_pos[(size_t)s * n + i] = v;
+    uint32_t *o = d.sort_rec + ((size_t)s * n + i) * 3;
+    o[0] = v;
+    o[1] = (a >> 16) | (b << 16);
+    o[2] = (b >> 16) | (c << 16);
 }
 
 static int sort_end_bit(int S)
@@ -212,6 +204,14 @@ size_t fer_sort_tmp_bytes(int n, int S)
     return bytes;
 }
 
+size_t fer_scan_tmp_bytes(size_t n)
+{
+    size_t bytes = 0;
+    rocprim::exclusive_scan((void *)nullptr, bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, n, rocprim::plus<uint32_t>(),
+                            (hipStream_t)0);
+    return bytes;
+}
+
 // host side: prepare the reference structures of all P-picture streams
 void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStream_t st)
 {
@@ -221,12 +221,15 @@ void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStr
     long long fw = (long long)(d.W >> 2) * ((d.H + FS_ROWS - 1) / FS_ROWS) * d.S;
     hipLaunchKernelGGL(k_features, dim3((unsigned)((fw + 3) / 4)), dim3(256), 0, st, d);
     int n = d.W * d.H;
+    const size_t nbins = (size_t)d.S * 16384 * d.kt + 1;
+    hipMemsetAsync(d.kol2_hist, 0, nbins * sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_sort_keys, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.keys_in, t.vals_in);
     size_t bytes = t.tmp_bytes;
     rocprim::radix_sort_pairs(t.tmp, bytes, t.keys_in, t.keys_out, t.vals_in, t.vals_out, (size_t)n * d.S, 0,
                               sort_end_bit(d.S), st);
-    int m = n > 16385 ? n : 16385;
-    hipLaunchKernelGGL(k_sort_finish, dim3((m + 255) / 256, d.S), dim3(256), 0, st, d, t.keys_out, t.vals_out);
+    bytes = t.scan_tmp_bytes;
+    rocprim::exclusive_scan(t.scan_tmp, bytes, d.kol2_hist, d.kol2, 0u, nbins, rocprim::plus<uint32_t>(), st);
+    hipLaunchKernelGGL(k_sort_finish, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.vals_out);
 }
 
 // ------------------------------------------------------------------ k_frame_sad
