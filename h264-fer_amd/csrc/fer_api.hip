@@ -155,7 +155,6 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     d.kt = (W + (1 << d.ktw_shift) - 1) >> d.ktw_shift;
     const size_t nbins = (size_t)S * 16384 * d.kt + 1;
     rc |= dalloc(c, &d.kol2, nbins);
-    rc |= dalloc(c, &d.kol2_hist, nbins);
     size_t nm = (size_t)d.nmb * S;
     rc |= dalloc(c, &d.mb_type, nm);
     rc |= dalloc(c, &d.mv, nm * 8);
@@ -191,12 +190,6 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     rc |= dalloc(c, &c->sort.keys_out, (size_t)n * S);
     rc |= dalloc(c, &c->sort.vals_in, (size_t)n * S);
     rc |= dalloc(c, &c->sort.vals_out, (size_t)n * S);
-    c->sort.scan_tmp_bytes = fer_scan_tmp_bytes(nbins);
-    {
-        uint8_t *stmp = nullptr;
-        rc |= dalloc(c, &stmp, c->sort.scan_tmp_bytes);
-        c->sort.scan_tmp = stmp;
-    }
     uint8_t *tmp = nullptr;
     rc |= dalloc(c, &tmp, c->sort.tmp_bytes);
     c->sort.tmp = tmp;

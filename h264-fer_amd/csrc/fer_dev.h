@@ -41,7 +41,6 @@ struct FerDev {
     // the first sorted record of stream s with sum a and tx >= t << ktw_shift (a tile of columns); the entry at
     // t == kt is the next bucket's first.  koliko[a] of the reference = kol2[(s*16384 + a)*kt] - s*W*H.
     uint32_t *kol2;      // [S*16384*kt + 1]
-    uint32_t *kol2_hist; // same size: (sum, column tile) histogram the index is the exclusive scan of
     int kt, ktw_shift;
     // per-MB side information (a20)
     int *mb_type;        // [S][nmb]
@@ -401,13 +400,13 @@ __device__ __forceinline__ int mc_chroma(const uint8_t *__restrict__ R, int Wc, 
 // (the arrays are allocated with 256 bytes of slack, so the trailing dword is always readable)
 __device__ __forceinline__ uint32_t load_u8x4(const uint8_t *__restrict__ p)
 {
-    const uint32_t *a = (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
+    const uint32_t *a = (const uint32_t *)(p - ((uintptr_t)p & 3));  // pointer arithmetic keeps the global address space
     uint32_t sh = (uint32_t)((uintptr_t)p & 3);
     return __builtin_amdgcn_alignbyte(a[1], a[0], sh);
 }
 __device__ __forceinline__ void load_u8x8(const uint8_t *__restrict__ p, uint32_t &lo, uint32_t &hi)
 {
-    const uint32_t *a = (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
+    const uint32_t *a = (const uint32_t *)(p - ((uintptr_t)p & 3));  // pointer arithmetic keeps the global address space
     uint32_t sh = (uint32_t)((uintptr_t)p & 3);
     uint32_t w0 = a[0], w1 = a[1], w2 = a[2];
     lo = __builtin_amdgcn_alignbyte(w1, w0, sh);

@@ -7,12 +7,9 @@ struct FerSortTmp {
     uint32_t *vals_in, *vals_out;
     void *tmp;
     size_t tmp_bytes;
-    void *scan_tmp;       // scratch of the exclusive scan that turns the (sum, tile) histogram into kol2
-    size_t scan_tmp_bytes;
 };
 
 size_t fer_sort_tmp_bytes(int n, int S);
-size_t fer_scan_tmp_bytes(size_t n);
 void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStream_t st);
 void fer_launch_frame_sad(const FerDev &d, hipStream_t st);
 void fer_launch_me_pre(const FerDev &d, hipStream_t st);

@@ -65,6 +65,14 @@ __device__ __forceinline__ void wl_insert(WList &L, int K, int lane, bool valid,
 // More than 64 survivors of step 2 or metrics >= 2^26 take the binary-search route instead.
 // v[u] < 0 marks an invalid candidate; pay(u) is the payload (packed vector) of the lane's
 // candidate u.  sel = 256 ints of 16-byte aligned LDS owned by the wavefront.
+// sel is private to ONE wavefront: its LDS operations execute in program order, so ordering them needs no
+// s_barrier (which would also be wrong inside the two-wavefront workgroups of k_me_resolve, whose wavefronts
+// call this a different number of times) -- only the compiler must not move them across.
+#define WAVE_LDS_SYNC()                                    \
+    do {                                                   \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                   \
+    } while (0)
 __device__ __forceinline__ int lds_rank64(const unsigned *p, unsigned mine)
 {
     const uint4 *q = (const uint4 *)p;
@@ -101,7 +109,7 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
         const unsigned mykey = lmin != 0x7fffffff ? ((unsigned)lmin << 6) | (unsigned)lane : 0xffffffffu;
         A[lane] = mykey;
         B[lane] = 0xffffffffu;
-        __syncthreads();
+        WAVE_LDS_SYNC();
         const int rk = lds_rank64(A, mykey);
         const unsigned long long hit = __ballot(rk == need - 1);
         int T0 = 0x7fffffff;  // fewer than `need` lanes hold anything: every candidate is needed
@@ -123,21 +131,21 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
         }
     }
     if (c <= 64) {
-        __syncthreads();
+        WAVE_LDS_SYNC();
         const unsigned mine = B[lane];
         const int mypay = Ci[lane];
         const int rk = lds_rank64(B, mine);
-        __syncthreads();
+        WAVE_LDS_SYNC();
         if (lane < c && rk < need) {
             A[rk] = mine >> 6;
             Di[rk] = mypay;
         }
-        __syncthreads();
+        WAVE_LDS_SYNC();
         if (lane < need) {
             L.m = (int)A[lane];
             L.xy = Di[lane];
         }
-        __syncthreads();
+        WAVE_LDS_SYNC();
         return;
     }
     // ---- general route: binary-search the need-th smallest metric with ballot counts, take everything
@@ -164,7 +172,7 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
     for (int u = 0; u < NB; u++) c_less += __popcll(__ballot(v[u] >= 0 && v[u] < T));
     const int take_eq = need - c_less;
     int nsel = 0, eq_seen = 0;
-    __syncthreads();
+    WAVE_LDS_SYNC();
 #pragma unroll
     for (int u = 0; u < NB; u++) {
         bool ok = v[u] >= 0;
@@ -180,7 +188,7 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
         nsel += __popcll(mt);
         eq_seen += __popcll(meq);
     }
-    __syncthreads();
+    WAVE_LDS_SYNC();
     int mk = lane < need ? key[lane] : INF_M, mxy = lane < need ? kxy[lane] : 0;
     int rank = 0;
     for (int i = 0; i < need; i++) {
@@ -191,12 +199,12 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
         key2[rank] = mk;
         kxy2[rank] = mxy;
     }
-    __syncthreads();
+    WAVE_LDS_SYNC();
     if (lane < need) {
         L.m = key2[lane];
         L.xy = kxy2[lane];
     }
-    __syncthreads();
+    WAVE_LDS_SYNC();
 }
 
 // ---- the 9-term feature distance of F/moestimation.cpp:267-276 on packed 16-bit pairs ----
@@ -303,7 +311,7 @@ __device__ __forceinline__ SadRow sad_row_load(const uint8_t *__restrict__ Ps, s
 {
     int xPi = iclamp(xP + (mvx >> 2), 0, W - 1), yPi = iclamp(yP + (mvy >> 2), 0, H - 1);
     const uint8_t *p = Ps + (size_t)((mvx & 3) + (mvy & 3) * 4) * ysz + (size_t)min(yPi + row, H - 1) * W + xPi;
-    const uint32_t *a = (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
+    const uint32_t *a = (const uint32_t *)(p - ((uintptr_t)p & 3));  // pointer arithmetic keeps the global address space
     SadRow r;
     r.w0 = a[0];
     r.w1 = a[1];
@@ -674,26 +682,27 @@ __device__ __forceinline__ void take_best(int best, int bestxy, int &bmin, int &
 // ------------------------------------------------------------------ k_me_resolve
 // The neighbour-dependent part of the search is a chain: a partition needs the final vectors
 // of its left, up, up-right and up-left neighbours.  It runs as ONE persistent launch per
-// picture: one wavefront per (stream, row of 8x8 partitions) walks its row left to right and
+// picture: one workgroup per (stream, row of 8x8 partitions) walks its row left to right and
 // follows the row above at the distance the prediction needs (3 partitions for partition 0,
 // whose P_Skip predictor reads the up-right MACROBLOCK; 2 for partitions 1 and 2; 1 for
-// partition 3).  Rows publish their progress through an agent-scope release store and wait
-// on the row above with an acquire load, so streams and rows advance independently instead
-// of meeting at a device-wide barrier (a kernel boundary) 639 times per picture.  Rows are
-// handed out by an atomic ticket in row-major order: the row a wavefront waits on was always
-// claimed earlier by a wavefront that is running or finished, so every wait terminates; a
-// bounded spin count turns anything unexpected into an error flag instead of a hang.
+// partition 3), so streams and rows advance independently instead of meeting at a device-wide
+// barrier (a kernel boundary) 639 times per picture.  Rows are handed out by an atomic ticket in
+// row-major order: the row a workgroup waits on was always claimed earlier by a workgroup that
+// is running or finished, so every wait terminates; a bounded spin count turns anything
+// unexpected into an error flag instead of a hang.
 //
-// Per partition the work is three rounds of loads:
-//   (1) everything that does not depend on the predictor (stage-2/3 candidate records of
-//       k_me_pre, box sums, source rows) -- requested one partition ahead,
-//   (2) the stage-1 feature records, (3) the SAD rows of the stage-1 and stage-2 survivors together.
+// A wavefront that waits on its predecessor runs alone on its SIMD, so every dependent
+// instruction costs its full latency.  The two searches of a partition are therefore split over
+// the two wavefronts of the workgroup: wavefront 0 makes the P_Skip test, runs stage 1 (feature
+// records around the predictor, top 17, their SADs), merges and publishes; wavefront 1 re-ranks
+// the precomputed stage-2 set (top 33, their SADs) and the stage-3 survivors.  Both read the
+// neighbour vectors themselves; they meet twice per partition through LDS.
 // Everything after the vector of the partition is known (merge, mvd, final prediction,
 // snapping) is not on any other partition's dependency chain and lives in k_me_finish.
 #define ST1_UNROLL 7
 #define RES_SPIN_LIMIT (1 << 23)
 
-struct ResPre {  // predictor-independent operands of one partition
+struct ResPre {  // predictor-independent operands of one partition (role 1 needs all, role 0 the last two lines)
     int n2, n3;
     int2 e2[FER_ST2_CAP / 64];
     int c3x, c3y, c3s;
@@ -701,21 +710,25 @@ struct ResPre {  // predictor-independent operands of one partition
     uint32_t src0, src1;
 };
 
-__device__ __forceinline__ void res_prefetch(const FerDev &d, int s, int gx, int gy, int lane, ResPre &p)
+__device__ __forceinline__ void res_prefetch(const FerDev &d, int s, int gx, int gy, int lane, int role, ResPre &p)
 {
     const int mb = (gy >> 1) * d.mbw + (gx >> 1), part = (gy & 1) * 2 + (gx & 1);
     const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
-    p.n2 = min(d.st2n[pidx], FER_ST2_CAP);
-    p.n3 = (d.dbg & 64) ? 0 : d.st3n[pidx];
-    const int2 *c2 = (const int2 *)(d.st2 + pidx * FER_ST2_CAP * 2);
-#pragma unroll
-    for (int u = 0; u < FER_ST2_CAP / 64; u++) p.e2[u] = c2[u * 64 + lane];  // slots >= n2 hold stale data, masked later
-    const int *c3 = d.st3 + pidx * 33 * 3;
+    p.n2 = p.n3 = 0;
     p.c3x = p.c3y = p.c3s = 0;
-    if (lane < 33) {
-        p.c3x = c3[lane * 3];
-        p.c3y = c3[lane * 3 + 1];
-        p.c3s = c3[lane * 3 + 2];
+#pragma unroll
+    for (int u = 0; u < FER_ST2_CAP / 64; u++) p.e2[u] = make_int2(0, 0);
+    if (role == 1) {
+        p.n2 = min(d.st2n[pidx], FER_ST2_CAP);
+        p.n3 = (d.dbg & 64) ? 0 : d.st3n[pidx];
+        const int2 *c2 = (const int2 *)(d.st2 + pidx * FER_ST2_CAP * 2);
+#pragma unroll
+        for (int u = 0; u < FER_ST2_CAP / 64; u++) p.e2[u] = c2[u * 64 + lane];  // slots >= n2 hold stale data, masked later
+        const int *c3 = d.st3 + pidx * 33 * 3;
+        const int l3 = min(lane, 32);
+        p.c3x = c3[l3 * 3];
+        p.c3y = c3[l3 * 3 + 1];
+        p.c3s = c3[l3 * 3 + 2];
     }
 #pragma unroll
     for (int k = 0; k < 5; k++) p.su[k] = d.suma[pidx * 5 + k];
@@ -755,18 +768,19 @@ __device__ __forceinline__ void predict_nbr(bool vA, int A, bool vB, int B, bool
     predict_core(mx, my, ref, ox, oy);
 }
 
-// decision of partition (gx, gy): returns the packed vector; skip = the macroblock became P_Skip (partition 0 only)
-template <int WIN>
-__device__ __forceinline__ int resolve_part(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
-                                            int *sel_lds, bool &skip, bool probe, long long *tp)
+// wave-level first minimum of per-lane (cost << 6 | list index) keys: the key and its vector
+__device__ __forceinline__ void wave_best(int best, int bestxy, int &wkey, int &wxy)
 {
-#define RP_MARK(k)                        \
-    if (probe) {                          \
-        long long now_ = wall_clock64();  \
-        tp[k] += now_ - tm_;              \
-        tm_ = now_;                       \
-    }
-    long long tm_ = probe ? wall_clock64() : 0;
+    wkey = wave_min(best);
+    wxy = 0;
+    if (wkey != 0x7fffffff) wxy = lane_bcast(bestxy, __ffsll((long long)__ballot(best == wkey)) - 1);
+}
+
+// role 0: P_Skip test (partition 0) and stage 1.  Returns skip; otherwise the best stage-1 (key, vector).
+template <int WIN>
+__device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
+                                               int *sel_lds, int &skipw, int &wkey, int &wxy)
+{
     const int window = WIN ? WIN : d.window;
     const int mbx = gx >> 1, mby = gy >> 1, part = (gy & 1) * 2 + (gx & 1);
     const int mb = mby * d.mbw + mbx;
@@ -778,7 +792,9 @@ __device__ __forceinline__ int resolve_part(const FerDev &d, int s, int gx, int 
     const uint16_t *Fs = d.feat + (size_t)s * 96 * ysz;
     const int xp = mbx << 4, yp = mby << 4;
     const int sx = gx * 8, sy = gy * 8;
-    skip = false;
+    wkey = 0x7fffffff;
+    wxy = 0;
+    skipw = 0;
 
     if (part == 0) {
         // ---- P_Skip candidate, F/mode_pred.cpp:381-402 + F/moestimation.cpp:402-425
@@ -813,34 +829,20 @@ __device__ __forceinline__ int resolve_part(const FerDev &d, int s, int gx, int 
                 (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
             Cb[(size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl] = (uint8_t)mc_chroma(RCb, Wc, Hc, xp / 2, yp / 2, cxl, cyl, smx, smy);
             Cr[(size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl] = (uint8_t)mc_chroma(RCr, Wc, Hc, xp / 2, yp / 2, cxl, cyl, smx, smy);
-            skip = true;
-            return pack_xy(smx, smy);
+            skipw = pack_xy(smx, smy);
+            return true;
         }
     }
 
-    RP_MARK(0)
-    // ---- search of this 8x8 partition as part of a P_8x8ref0 macroblock
+    // ---- stage 1: +-W/16 around the predictor, all 16 fractional planes (K = 17)
     const SuPk sp = su_pack(P.su);
     int mvpx, mvpy;
     predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
     const int genx = mvpx >> 2, geny = mvpy >> 2;
-    int bx = 0, by = 0, bmin = 2000000000;
-
-    // ---- round (2): stage 1, +-W/16 around the predictor, all 16 fractional planes (K = 17)
-    WList L1, L2;
-    L1.m = L2.m = INF_M;
-    L1.xy = L2.xy = 0;
+    WList L1;
+    L1.m = INF_M;
+    L1.xy = 0;
     const int r1 = window / 16, n1 = 2 * r1 + 1, tot1 = (d.dbg & 16) ? 0 : n1 * n1 * 16;
-    const bool st2on = !d.basic && !(d.dbg & 32);
-    // stage 2 (K = 33): the precomputed candidate set weighted by the distance to the predictor
-    int m2[FER_ST2_CAP / 64];
-#pragma unroll
-    for (int u = 0; u < FER_ST2_CAP / 64; u++) {
-        int cc = u * 64 + lane;
-        int tx = P.e2[u].x >> 16, ty = (int)(short)(P.e2[u].x & 0xffff);  // k_me_pre stores (tx << 16) | (ty & 0xffff)
-        m2[u] = (st2on && cc < P.n2) ? (iabs(tx - genx) + iabs(ty - geny) + 4) * P.e2[u].y : -1;
-    }
-    auto pay2 = [&](int u) { return pack_xy((P.e2[u].x >> 16) * 4, (int)(short)(P.e2[u].x & 0xffff) * 4); };
     auto pay1 = [&](int u) {
         int cc = u * 64 + lane;
         int frac = cc & 15, pos = cc >> 4;
@@ -865,12 +867,7 @@ __device__ __forceinline__ int resolve_part(const FerDev &d, int s, int gx, int 
             int mm = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist_w(fr[u].a, fr[u].b, fr[u].c, sp);
             m[u] = ok ? mm : -1;
         }
-        RP_MARK(1)
-        // the stage-2 selection runs while the feature records above are in flight
-        select_topk<FER_ST2_CAP / 64>(m2, 33, lane, sel_lds, L2, pay2);
-        RP_MARK(2)
         select_topk<ST1_UNROLL>(m, 17, lane, sel_lds, L1, pay1);
-        RP_MARK(3)
     } else {
         for (int base = 0; base < tot1; base += 64) {
             int cc = base + lane;
@@ -882,38 +879,98 @@ __device__ __forceinline__ int resolve_part(const FerDev &d, int s, int gx, int 
             if (ok) m = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, sp);
             wl_insert(L1, 17, lane, ok, m, pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2)));
         }
-        select_topk<FER_ST2_CAP / 64>(m2, 33, lane, sel_lds, L2, pay2);
     }
-    // ---- round (3): SAD rows of both survivor lists, then the ordered first-minimum over
-    // stage 1, stage 2, stage 3 (strict <, F/moestimation.cpp:460-520)
     const int cnt1 = __popcll(__ballot(lane < 17 && L1.m < 100000000));
-    const int cnt2 = __popcll(__ballot(lane < 33 && L2.m < 100000000));
-    int b1, b1xy, b2, b2xy;
+    int b1, b1xy;
     sad_keys<17>(L1, cnt1, lane, Ps, ysz, W, H, sx, sy, P.src0, P.src1, mvpx, mvpy, b1, b1xy);
-    sad_keys<33>(L2, cnt2, lane, Ps, ysz, W, H, sx, sy, P.src0, P.src1, mvpx, mvpy, b2, b2xy);
-    RP_MARK(4)
-    take_best(b1, b1xy, bmin, bx, by);
-    take_best(b2, b2xy, bmin, bx, by);
-    if (st2on) {
-        int key = 0x7fffffff;
-        if (lane < P.n3) key = ((P.c3s + iabs(P.c3x - mvpx) + iabs(P.c3y - mvpy)) << 6) | lane;
-        take_best(key, pack_xy(P.c3x, P.c3y), bmin, bx, by);
+    wave_best(b1, b1xy, wkey, wxy);
+    return false;
+}
+
+// role 1: stage 2 (K = 33 of the precomputed candidate set, weighted by the distance to the predictor)
+// and stage 3 (precomputed survivors): best (key, vector) of each
+template <int WIN>
+__device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
+                                                int *sel_lds, int &k2, int &xy2, int &k3, int &xy3)
+{
+    const int W = d.W, H = d.H;
+    const size_t ysz = d.ysz;
+    const uint8_t *Ps = d.interp + (size_t)s * 16 * ysz;
+    const int sx = gx * 8, sy = gy * 8;
+    k2 = k3 = 0x7fffffff;
+    xy2 = xy3 = 0;
+    if (d.basic || (d.dbg & 32)) return;
+    int mvpx, mvpy;
+    predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
+    const int genx = mvpx >> 2, geny = mvpy >> 2;
+    int m2[FER_ST2_CAP / 64];
+#pragma unroll
+    for (int u = 0; u < FER_ST2_CAP / 64; u++) {
+        int cc = u * 64 + lane;
+        int tx = P.e2[u].x >> 16, ty = (int)(short)(P.e2[u].x & 0xffff);  // k_me_walk stores (tx << 16) | (ty & 0xffff)
+        m2[u] = cc < P.n2 ? (iabs(tx - genx) + iabs(ty - geny) + 4) * P.e2[u].y : -1;
     }
-    RP_MARK(5)
-#undef RP_MARK
-    return pack_xy(bx, by);
+    auto pay2 = [&](int u) { return pack_xy((P.e2[u].x >> 16) * 4, (int)(short)(P.e2[u].x & 0xffff) * 4); };
+    WList L2;
+    select_topk<FER_ST2_CAP / 64>(m2, 33, lane, sel_lds, L2, pay2);
+    const int cnt2 = __popcll(__ballot(lane < 33 && L2.m < 100000000));
+    int b2, b2xy;
+    sad_keys<33>(L2, cnt2, lane, Ps, ysz, W, H, sx, sy, P.src0, P.src1, mvpx, mvpy, b2, b2xy);
+    wave_best(b2, b2xy, k2, xy2);
+    int key = 0x7fffffff;
+    if (lane < P.n3) key = ((P.c3s + iabs(P.c3x - mvpx) + iabs(P.c3y - mvpy)) << 6) | lane;
+    wave_best(key, pack_xy(P.c3x, P.c3y), k3, xy3);
+}
+
+// neighbour lookup of partition `part` of macroblock (mbx, mby): like nbr_locate, without divisions
+__device__ __forceinline__ void nbr_locate_xy(int mbw, int mbx, int mby, int xN, int yN, bool &valid, int &mbN, int &q)
+{
+    const int cur = mby * mbw + mbx;
+    int xW = xN, yW = yN;
+    mbN = cur;
+    q = 0;
+    valid = false;
+    if (xW > 15 && yW >= 0) return;
+    if (yW > 15) return;
+    valid = true;
+    if (!(xW >= 0 && xW < 16 && yW >= 0)) {
+        if (xW >= 0 && xW < 16) {  // above
+            mbN = cur - mbw;
+            valid = mby > 0;
+            yW += 16;
+        } else if (xW > 15) {      // above right
+            mbN = cur - mbw + 1;
+            valid = mby > 0 && mbx + 1 < mbw;
+            xW -= 16;
+            yW += 16;
+        } else if (yW < 0) {       // above left
+            mbN = cur - mbw - 1;
+            valid = mby > 0 && mbx > 0;
+            xW += 16;
+            yW += 16;
+        } else {                   // left
+            mbN = cur - 1;
+            valid = mbx > 0;
+            xW += 16;
+        }
+    }
+    q = ((yW >> 3) << 1) + (xW >> 3);
 }
 
 template <int WIN>
-__global__ __launch_bounds__(64, 4) void k_me_resolve(FerDev d)
+__global__ __launch_bounds__(128, 2) void k_me_resolve(FerDev d)
 {
-    __shared__ __attribute__((aligned(16))) int sel_lds[256];
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) int sel_all[2][256];
+    __shared__ int xch[8];
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int *sel_lds = sel_all[role];
     const int gw = d.mbw * 2, gh = d.mbh * 2;
     // row ticket: rows of all streams in row-major order
-    int t = 0;
-    if (lane == 0) t = atomicAdd(d.chain, 1);
-    t = __builtin_amdgcn_readfirstlane(t);
+    if (threadIdx.x == 0) xch[0] = atomicAdd(d.chain, 1);
+    __syncthreads();
+    const int t = xch[0];
+    __syncthreads();
     const int gy = t / d.S, s = t - gy * d.S;
     if (gy >= gh) return;
     if (d.hdr[s * 4 + 3] != 0) return;  // not a P picture: nobody waits on these rows
@@ -923,31 +980,39 @@ __global__ __launch_bounds__(64, 4) void k_me_resolve(FerDev d)
     const unsigned serial = (unsigned)d.serial & 0x7fffffffu;
 
 #ifdef FER_PROBE
-    const bool probe = (d.dbg & 128) && s == 0 && gy == gh / 2;  // one wavefront reports where its time goes
+    const bool probe = (d.dbg & 128) && s == 0 && gy == gh / 2;  // one row reports where its time goes
+#define PR_MARK(k)                        \
+    if (probe) {                          \
+        long long now_ = wall_clock64();  \
+        tacc[k] += now_ - tmark;          \
+        tmark = now_;                     \
+    }
 #else
     const bool probe = false;
+#define PR_MARK(k)
 #endif
-    long long tacc[4] = {0, 0, 0, 0}, tmark = 0, tp[6] = {0, 0, 0, 0, 0, 0};
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tmark = 0;
     int prevw = 0;  // vector of the previous partition of this row (the left neighbour A)
     bool skip = false, timeout = false;
     for (int gx = 0; gx < gw; gx++) {
-        const int part = (gy & 1) * 2 + (gx & 1);
-        const int mb = (gy >> 1) * d.mbw + (gx >> 1);
         if (probe) tmark = wall_clock64();
+        const int part = (gy & 1) * 2 + (gx & 1);
+        const int mbx = gx >> 1, mby = gy >> 1;
+        const int mb = mby * d.mbw + mbx;
         // the lane id is made opaque per iteration: otherwise dozens of lane-derived constants of the loop body
         // are hoisted out of the loop and spilled
         int ln = lane;
         asm volatile("" : "+v"(ln));
         ResPre cur;  // requested before the neighbours are polled: both round trips overlap
-        res_prefetch(d, s, gx, gy, ln, cur);
+        res_prefetch(d, s, gx, gy, ln, role, cur);
         // neighbours in the row above: lane 0 = B, 1 = C, 2 = D, 3 = C of the 16x16 (P_Skip) predictor
         const int x = (part & 1) * 8, y = (part >> 1) * 8;
         bool val = false;
         int mbN = 0, q = 0;
-        if (lane < 3 || (lane == 3 && part == 0)) {
-            int nx = lane == 0 ? x : (lane == 1 ? x + 8 : (lane == 2 ? x - 1 : 16));
-            int ny = lane == 3 ? -1 : y - 1;
-            nbr_locate(d.mbw, mb, nx, ny, val, mbN, q);
+        if (ln < 3 || (ln == 3 && part == 0)) {
+            int nx = ln == 0 ? x : (ln == 1 ? x + 8 : (ln == 2 ? x - 1 : 16));
+            int ny = ln == 3 ? -1 : y - 1;
+            nbr_locate_xy(d.mbw, mbx, mby, nx, ny, val, mbN, q);
         }
         unsigned wl = 0, wh = 0;
         for (int it = 0;; it++) {
@@ -963,13 +1028,9 @@ __global__ __launch_bounds__(64, 4) void k_me_resolve(FerDev d)
                 timeout = true;
                 break;
             }
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(2);
         }
-        if (probe) {
-            long long now = wall_clock64();
-            tacc[0] += now - tmark;
-            tmark = now;
-        }
+        PR_MARK(0)
         ResNbr N;
         const unsigned long long vm = __ballot(val);
         N.vA = gx > 0;
@@ -986,34 +1047,74 @@ __global__ __launch_bounds__(64, 4) void k_me_resolve(FerDev d)
             skip = (lane_bcast((int)wh, 0) & CH_SKIP) != 0;
             if (skip) prevw = N.B;
         }
-        if (part == 0 || !skip) {
-            bool sk;
-            int r = resolve_part<WIN>(d, s, gx, gy, ln, cur, N, sel_lds, sk, probe, tp);
-            prevw = r;
-            if (probe) {
-                long long now = wall_clock64();
-                tacc[1] += now - tmark;
-                tmark = now;
-            }
-            unsigned long long w = (unsigned)r | ((unsigned long long)(serial | (sk ? CH_SKIP : 0u)) << 32);
-            if (part == 0) {
-                skip = sk;
-                if (lane == 0) mbt[mb] = sk ? FER_P_SKIP : FER_P_8x8ref0;  // also clears a P_Skip left by the previous picture
-                if (sk && lane == 0) atomicAdd(&d.stats[s * 5 + 0], 1);
-            }
-            const int nq = sk ? 4 : 1, q0 = sk ? 0 : part;
-            if (lane < nq) {
-                *(int *)(mvs + ((size_t)mb * 4 + q0 + lane) * 2) = r;
-                __hip_atomic_store(chw + (size_t)mb * 4 + q0 + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (part == 0 || !skip) {  // the same decision in both wavefronts: the barriers below are uniform
+            if (role == 0) {
+                int skipw, k1, xy1;
+                bool sk = resolve_stage1<WIN>(d, s, gx, gy, ln, cur, N, sel_lds, skipw, k1, xy1);
+                PR_MARK(1)
+                __syncthreads();  // stage 2/3 results are in xch[0..3]
+                PR_MARK(2)
+                int r = skipw;
+                if (!sk) {  // ordered first minimum over stage 1, 2, 3 (strict <, F/moestimation.cpp:460-520)
+                    int bmin = 2000000000;
+                    r = 0;
+                    if (k1 != 0x7fffffff && (k1 >> 6) < bmin) {
+                        bmin = k1 >> 6;
+                        r = xy1;
+                    }
+                    const int k2 = xch[0], k3 = xch[2];
+                    if (k2 != 0x7fffffff && (k2 >> 6) < bmin) {
+                        bmin = k2 >> 6;
+                        r = xch[1];
+                    }
+                    if (k3 != 0x7fffffff && (k3 >> 6) < bmin) {
+                        bmin = k3 >> 6;
+                        r = xch[3];
+                    }
+                }
+                if (ln == 0) {
+                    xch[4] = r;
+                    xch[5] = sk;
+                }
+                unsigned long long w = (unsigned)r | ((unsigned long long)(serial | (sk ? CH_SKIP : 0u)) << 32);
+                if (part == 0 && ln == 0) {
+                    mbt[mb] = sk ? FER_P_SKIP : FER_P_8x8ref0;  // also clears a P_Skip left by the previous picture
+                    if (sk) atomicAdd(&d.stats[s * 5 + 0], 1);
+                }
+                const int nq = sk ? 4 : 1, q0 = sk ? 0 : part;
+                if (ln < nq) {
+                    __hip_atomic_store(chw + (size_t)mb * 4 + q0 + ln, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *(int *)(mvs + ((size_t)mb * 4 + q0 + ln) * 2) = r;
+                }
+                PR_MARK(3)
+                __syncthreads();
+                PR_MARK(4)
+                prevw = r;
+                if (part == 0) skip = sk;
+            } else {
+                int k2, xy2, k3, xy3;
+                resolve_stage23<WIN>(d, s, gx, gy, ln, cur, N, sel_lds, k2, xy2, k3, xy3);
+                if (ln == 0) {
+                    xch[0] = k2;
+                    xch[1] = xy2;
+                    xch[2] = k3;
+                    xch[3] = xy3;
+                }
+                PR_MARK(1)
+                __syncthreads();
+                PR_MARK(2)
+                __syncthreads();  // the merged result is in xch[4..5]
+                PR_MARK(4)
+                prevw = xch[4];
+                if (part == 0) skip = xch[5] != 0;
             }
         }
-        if (probe) tacc[2] += wall_clock64() - tmark;
     }
     if (probe && lane == 0) {
-        for (int k = 0; k < 3; k++) d.timing[k] = tacc[k];
-        d.timing[3] = gw;
-        for (int k = 0; k < 6; k++) d.timing[4 + k] = tp[k];
+        for (int k = 0; k < 6; k++) d.timing[role * 8 + k] = tacc[k];
+        d.timing[role * 8 + 7] = gw;
     }
+#undef PR_MARK
     if (timeout && lane == 0) atomicOr(&d.status[s], FER_ERR_CHAIN_TIMEOUT);
 }
 
@@ -1140,9 +1241,9 @@ void fer_launch_me_resolve(const FerDev &d, hipStream_t st)
     hipMemsetAsync(d.chain, 0, sizeof(int), st);
     dim3 g(gh * d.S);
     if (d.window == 32)
-        hipLaunchKernelGGL(k_me_resolve<32>, g, dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_me_resolve<32>, g, dim3(128), 0, st, d);
     else if (d.window == 16)
-        hipLaunchKernelGGL(k_me_resolve<16>, g, dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_me_resolve<16>, g, dim3(128), 0, st, d);
     else
-        hipLaunchKernelGGL(k_me_resolve<0>, g, dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_me_resolve<0>, g, dim3(128), 0, st, d);
 }

@@ -131,10 +131,10 @@ __global__ __launch_bounds__(256) void k_features(FerDev d)
                     uint32_t a = (uint32_t)k0 | ((uint32_t)k1 << 16), b = (uint32_t)k2 | ((uint32_t)k3 << 16),
                              c = (uint32_t)k4;
                     size_t pos = (size_t)yo * W + x;
-                    uint32_t *o = out + (pos * 16 + f) * 3;
-                    o[0] = a;
-                    o[1] = b;
-                    o[2] = c;
+                    uint32_t *o = out + (pos * 16 + f) * 3;  // 420 MB per picture, read back much later: streaming stores
+                    __builtin_nontemporal_store(a, o);
+                    __builtin_nontemporal_store(b, o + 1);
+                    __builtin_nontemporal_store(c, o + 2);
                     if (f == 0) {
                         uint32_t *o0 = out0 + pos * 3;
                         o0[0] = a;
@@ -148,45 +148,79 @@ __global__ __launch_bounds__(256) void k_features(FerDev d)
 }
 
 // ------------------------------------------------------------------ sort by 8x8 sum
-// keys in arrival order b = tx*H + ty (the reference scans columns, F/moestimation.cpp:142-151);
-// the same pass counts the positions per (sum, column tile) for the two-level bucket index
+// keys in arrival order b = tx*H + ty (the reference scans columns, F/moestimation.cpp:142-151)
 __global__ void k_sort_keys(FerDev d, uint32_t *keys, uint32_t *vals)
 {
     const int s = blockIdx.y;
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     int n = d.W * d.H;
     if (b >= n) return;
-    uint32_t *hist = d.kol2_hist + (size_t)s * 16384 * d.kt;
     if (d.hdr[s * 4 + 3] != 0) {  // not a P picture: keep the segment populated so the device-wide order stays aligned
         keys[(size_t)s * n + b] = (uint32_t)s << 15;
         vals[(size_t)s * n + b] = 0;
-        if ((b & 63) == 0) atomicAdd(hist, (uint32_t)min(64, n - b));
         return;
     }
     int tx = b / d.H, ty = b % d.H;
     uint16_t k = d.feat0[((size_t)s * d.ysz + (size_t)ty * d.W + tx) * 6];
     keys[(size_t)s * n + b] = ((uint32_t)s << 15) | k;  // one device-wide sort: stream id above the 15-bit sum
     vals[(size_t)s * n + b] = ((uint32_t)tx << 16) | (uint32_t)ty;
-    atomicAdd(hist + (size_t)k * d.kt + (tx >> d.ktw_shift), 1u);
     if (k == 0) atomicOr(&d.status[s], FER_ERR_ZERO_SUM);  // the reference mis-files sum 0 (F/moestimation.cpp:153)
 }
 
-__global__ void k_sort_finish(FerDev d, const uint32_t *svals)
+// Payload of the sorted order + the two-level bucket index.  Record i opens every (sum, column tile) bin
+// after its predecessor's up to its own: kol2[bin] = i for those bins (lower bound of the bin in the sorted
+// order).  Gaps are short except at the ends of the sum range; long ones are filled by the whole wavefront.
+__global__ __launch_bounds__(256) void k_sort_finish(FerDev d, const uint32_t *skeys, const uint32_t *svals)
 {
     const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int n = d.W * d.H;
-    if (i >= n) return;
-    uint32_t v = svals[(size_t)s * n + i];
-    int tx = v >> 16, ty = v & 0xffff;
-    const uint32_t *r = (const uint32_t *)(d.feat0 + ((size_t)s * d.ysz + (size_t)ty * d.W + tx) * 6);
-    uint32_t a = r[0], b = r[1], c = r[2];  // k0|k1<<16, k2|k3<<16, k4
-    d.sort_pos[(size_t)s * n + i] = v;
-    uint32_t *o = d.sort_rec + ((size_t)s * n + i) * 3;
-    o[0] = v;
-    o[1] = (a >> 16) | (b << 16);
-    o[2] = (b >> 16) | (c << 16);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = d.W * d.H;
+    const int nb = 16384 * d.kt;
+    uint32_t *kol2 = d.kol2 + (size_t)s * nb;
+    const size_t g0 = (size_t)s * n;
+    int gap_lo = 0, gap_hi = 0;  // bins [gap_lo, gap_hi) get value gval
+    uint32_t gval = 0;
+    if (i < n) {
+        uint32_t v = svals[g0 + i];
+        int tx = v >> 16, ty = v & 0xffff;
+        const uint32_t *r = (const uint32_t *)(d.feat0 + ((size_t)s * d.ysz + (size_t)ty * d.W + tx) * 6);
+        uint32_t a = r[0], b = r[1], c = r[2];  // k0|k1<<16, k2|k3<<16, k4
+        d.sort_pos[g0 + i] = v;
+        uint32_t *o = d.sort_rec + (g0 + i) * 3;
+        o[0] = v;
+        o[1] = (a >> 16) | (b << 16);
+        o[2] = (b >> 16) | (c << 16);
+        int bin = (int)(skeys[g0 + i] & 0x7fff) * d.kt + (tx >> d.ktw_shift);
+        int prev = -1;
+        if (i > 0) {
+            uint32_t pv = svals[g0 + i - 1];
+            prev = (int)(skeys[g0 + i - 1] & 0x7fff) * d.kt + (int)((pv >> 16) >> d.ktw_shift);
+        }
+        gap_lo = prev + 1;
+        gap_hi = bin + 1;
+        gval = (uint32_t)(g0 + i);
+    }
+    // the last record also closes the index: every bin after its own, and the end marker, start at the segment end
+    const bool tail = i == n - 1;
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) {
+            if (!__any(tail)) break;
+            gap_lo = tail ? gap_hi : 0;
+            gap_hi = tail ? nb + 1 : 0;
+            gval = (uint32_t)(g0 + n);
+        }
+        unsigned long long big = __ballot(gap_hi - gap_lo > 8);
+        if (gap_hi - gap_lo <= 8)
+            for (int b = gap_lo; b < gap_hi; b++) kol2[b] = gval;
+        while (big) {
+            int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            int lo = __shfl(gap_lo, src), hi = __shfl(gap_hi, src);
+            uint32_t val = (uint32_t)__shfl((int)gval, src);
+            for (int b = lo + (threadIdx.x & 63); b < hi; b += 64) kol2[b] = val;
+        }
+    }
 }
 
 static int sort_end_bit(int S)
@@ -204,14 +238,6 @@ size_t fer_sort_tmp_bytes(int n, int S)
     return bytes;
 }
 
-size_t fer_scan_tmp_bytes(size_t n)
-{
-    size_t bytes = 0;
-    rocprim::exclusive_scan((void *)nullptr, bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, n, rocprim::plus<uint32_t>(),
-                            (hipStream_t)0);
-    return bytes;
-}
-
 // host side: prepare the reference structures of all P-picture streams
 void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStream_t st)
 {
@@ -221,15 +247,11 @@ void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStr
     long long fw = (long long)(d.W >> 2) * ((d.H + FS_ROWS - 1) / FS_ROWS) * d.S;
     hipLaunchKernelGGL(k_features, dim3((unsigned)((fw + 3) / 4)), dim3(256), 0, st, d);
     int n = d.W * d.H;
-    const size_t nbins = (size_t)d.S * 16384 * d.kt + 1;
-    hipMemsetAsync(d.kol2_hist, 0, nbins * sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_sort_keys, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.keys_in, t.vals_in);
     size_t bytes = t.tmp_bytes;
     rocprim::radix_sort_pairs(t.tmp, bytes, t.keys_in, t.keys_out, t.vals_in, t.vals_out, (size_t)n * d.S, 0,
                               sort_end_bit(d.S), st);
-    bytes = t.scan_tmp_bytes;
-    rocprim::exclusive_scan(t.scan_tmp, bytes, d.kol2_hist, d.kol2, 0u, nbins, rocprim::plus<uint32_t>(), st);
-    hipLaunchKernelGGL(k_sort_finish, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.vals_out);
+    hipLaunchKernelGGL(k_sort_finish, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.keys_out, t.vals_out);
 }
 
 // ------------------------------------------------------------------ k_frame_sad

@@ -13,8 +13,11 @@ g.fill_interpolated()
 g.profile(True)
 for _ in range(3):
     g.inter_encoding()
-if int(os.environ.get("FER_DBG", "0")) & 128:
+if int(os.environ.get("FER_DBG", "0")) & 128:  # needs a build with EXTRA=-DFER_PROBE
     t = g.read("TIMING")
-    print("probe row: us per partition: wait %.2f  decide %.2f  publish %.2f  (n=%d)" % (t[0] / t[3] / 100, t[1] / t[3] / 100, t[2] / t[3] / 100, t[3]))
-    print("  decide split: " + "  ".join("%s %.2f" % (n, t[4 + k] / t[3] / 100) for k, n in enumerate(["skiptest", "pred+m2+featissue", "select2", "select1", "sads", "best"])))
+    for role in (0, 1):
+        r = t[role * 8:role * 8 + 8]
+        n = max(int(r[7]), 1)
+        print("probe row, wavefront %d, us per partition: " % role + "  ".join(
+            "%s %.2f" % (nm, r[k] / n / 100) for k, nm in enumerate(["prefetch+poll", "stage", "barrier1", "merge+publish", "barrier2"])))
 print(os.environ.get("FER_DBG", "0"), {k: round(v[0] / 3, 2) for k, v in g.get_profile().items() if v[0] > 0})
