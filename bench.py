@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("FER_BENCH_STREAMS", "64")))
+    ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("FER_BENCH_STAGGER_MS", "0")),
+                    help="start offset between consecutive contexts (milliseconds)")
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("FER_BENCH_CONTEXTS", "2")),
                     help="encoder contexts per GPU, each on its own HIP stream and host thread (streams are split evenly)")
     ap.add_argument("--cpu-frames", type=int, default=3, help="pictures of the CPU-baseline sample (0 = skip)")
@@ -104,6 +106,11 @@ def main():
 
     def run_ctx(i):
         e, fr = encs[i], parts[i]
+        if i and args.stagger_ms > 0:
+            # contexts that run in lockstep compete for the same unit (HBM in the feature pass, VALU in the search);
+            # a start offset of a fraction of a picture puts one context's memory-bound kernels under the other's
+            # compute-bound ones.  The offset is inside the timed region.
+            time.sleep(i * args.stagger_ms / 1e3)
         for t in range(GOP):
             e.set_frames_device(fr[t].data_ptr())
             e.encode_picture_device(None)   # AUTO: selectNALUnitType semantics (IDR every GOP)

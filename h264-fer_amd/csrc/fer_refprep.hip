@@ -75,17 +75,34 @@ __global__ __launch_bounds__(256) void k_interp(FerDev d)
 // partial sums, and keeps the last 8 rows in registers; vertical sums come straight from that ring.
 // Samples beyond the picture replicate the last row / column (the reference pads by 8).
 #define FS_ROWS 64
-__device__ __forceinline__ void feat_hsum(const uint8_t *__restrict__ row, int x, int W, int &h8, int &h4, int &hc)
+// the 8 samples x..x+7 of a row as three aligned dwords (fetched without control flow; a row that
+// runs over the right picture edge reads into the next row, inside the allocation)
+struct FeatRow {
+    uint32_t w0, w1, w2;
+};
+__device__ __forceinline__ FeatRow feat_row_load(const uint8_t *__restrict__ row, int x)
 {
-    uint32_t lo, hi;
-    if (x + 7 < W) {
-        load_u8x8(row + x, lo, hi);
-    } else {
-        lo = hi = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            lo |= (uint32_t)row[min(x + j, W - 1)] << (8 * j);
-            hi |= (uint32_t)row[min(x + 4 + j, W - 1)] << (8 * j);
+    const uint8_t *p = row + x;
+    const uint32_t *a = (const uint32_t *)(p - ((uintptr_t)p & 3));
+    FeatRow r;
+    r.w0 = a[0];
+    r.w1 = a[1];
+    r.w2 = a[2];
+    return r;
+}
+// horizontal partial sums: all 8 samples, the left 4, and samples {0,1,4,5}; nv = samples left of the right edge
+__device__ __forceinline__ void feat_hsum(const FeatRow &r, int sh, int nv, int &h8, int &h4, int &hc)
+{
+    uint32_t lo = __builtin_amdgcn_alignbyte(r.w1, r.w0, (uint32_t)sh);
+    uint32_t hi = __builtin_amdgcn_alignbyte(r.w2, r.w1, (uint32_t)sh);
+    if (__any(nv < 8)) {  // the reference pads by replicating the last column
+        if (nv < 8) {
+            unsigned long long v = ((unsigned long long)hi << 32) | lo;
+            unsigned long long last = (v >> (8 * (nv - 1))) & 0xffull;
+            unsigned long long keep = (1ull << (8 * nv)) - 1ull;
+            v = (v & keep) | ((last * 0x0101010101010101ull) & ~keep);
+            lo = (uint32_t)v;
+            hi = (uint32_t)(v >> 32);
         }
     }
     h4 = (int)__builtin_amdgcn_sad_u8(lo, 0u, 0u);
@@ -109,38 +126,44 @@ __global__ __launch_bounds__(256) void k_features(FerDev d)
     const int y0 = strip * FS_ROWS, y1 = min(y0 + FS_ROWS, H);  // output rows [y0, y1)
     uint32_t *out = (uint32_t *)(d.feat + (size_t)s * 96 * d.ysz);
     uint32_t *out0 = (uint32_t *)(d.feat0 + (size_t)s * 6 * d.ysz);
+    const int sh = (int)((uintptr_t)(P + x) & 3);  // W is a multiple of 16: the same byte offset in every row
+    const int nv = W - x;
     int h8[8], h4[8], hc[8];
     for (int base = 0; base < FS_ROWS + 8; base += 8) {
+        if (y0 + base - 7 >= y1) break;
+        // the 8 input rows of this round are requested together; a row at a time would leave the wavefront
+        // waiting on one memory round trip per output row
+        FeatRow rr[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) rr[j] = feat_row_load(P + (size_t)min(y0 + base + j, H - 1) * W, x);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int y = y0 + base + j;  // input row (clamped), completes the window of output row y - 7
-            if (y - 7 < y1) {
-                feat_hsum(P + (size_t)min(y, H - 1) * W, x, W, h8[j], h4[j], hc[j]);
-                const int yo = y - 7;
-                if (yo >= y0) {
-                    // slot of window row r (picture row yo + r) is (j + 1 + r) & 7
-                    int k0 = 0, k2 = 0, k4 = 0;
+            feat_hsum(rr[j], sh, nv, h8[j], h4[j], hc[j]);
+            const int yo = y - 7;
+            if (yo >= y0 && yo < y1) {
+                // slot of window row r (picture row yo + r) is (j + 1 + r) & 7
+                int k0 = 0, k2 = 0, k4 = 0;
 #pragma unroll
-                    for (int r = 0; r < 8; r++) {
-                        k0 += h8[r];
-                        k2 += h4[r];
-                        k4 += hc[r];
-                    }
-                    int k1 = h8[(j + 1) & 7] + h8[(j + 2) & 7] + h8[(j + 3) & 7] + h8[(j + 4) & 7];
-                    int k3 = h8[(j + 1) & 7] + h8[(j + 2) & 7] + h8[(j + 5) & 7] + h8[(j + 6) & 7];
-                    uint32_t a = (uint32_t)k0 | ((uint32_t)k1 << 16), b = (uint32_t)k2 | ((uint32_t)k3 << 16),
-                             c = (uint32_t)k4;
-                    size_t pos = (size_t)yo * W + x;
-                    uint32_t *o = out + (pos * 16 + f) * 3;  // 420 MB per picture, read back much later: streaming stores
-                    __builtin_nontemporal_store(a, o);
-                    __builtin_nontemporal_store(b, o + 1);
-                    __builtin_nontemporal_store(c, o + 2);
-                    if (f == 0) {
-                        uint32_t *o0 = out0 + pos * 3;
-                        o0[0] = a;
-                        o0[1] = b;
-                        o0[2] = c;
-                    }
+                for (int r = 0; r < 8; r++) {
+                    k0 += h8[r];
+                    k2 += h4[r];
+                    k4 += hc[r];
+                }
+                int k1 = h8[(j + 1) & 7] + h8[(j + 2) & 7] + h8[(j + 3) & 7] + h8[(j + 4) & 7];
+                int k3 = h8[(j + 1) & 7] + h8[(j + 2) & 7] + h8[(j + 5) & 7] + h8[(j + 6) & 7];
+                uint32_t a = (uint32_t)k0 | ((uint32_t)k1 << 16), b = (uint32_t)k2 | ((uint32_t)k3 << 16),
+                         c = (uint32_t)k4;
+                size_t pos = (size_t)yo * W + x;
+                uint32_t *o = out + (pos * 16 + f) * 3;  // 420 MB per picture, read back much later: streaming stores
+                __builtin_nontemporal_store(a, o);
+                __builtin_nontemporal_store(b, o + 1);
+                __builtin_nontemporal_store(c, o + 2);
+                if (f == 0) {
+                    uint32_t *o0 = out0 + pos * 3;
+                    o0[0] = a;
+                    o0[1] = b;
+                    o0[2] = c;
                 }
             }
         }
