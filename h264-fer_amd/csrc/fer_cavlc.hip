@@ -13,6 +13,8 @@
 template <bool WRITE>
 __global__ __launch_bounds__(64) void k_cavlc(FerDev d)
 {
+    __shared__ int16_t stage[16 * 64];  // coefficients of the block being coded, one column per thread
+    int16_t *st = stage + threadIdx.x;
     const int s = blockIdx.y;
     const int mb = blockIdx.x * blockDim.x + threadIdx.x;
     if (mb > d.nmb) return;
@@ -86,19 +88,19 @@ __global__ __launch_bounds__(64) void k_cavlc(FerDev d)
     if (cbpL > 0 || cbpC > 0 || i16) {
         bw_se<WRITE>(w, 0);  // mb_qp_delta
         // residual block order of F/residual.cpp:300-372
-        if (i16) cavlc_block<WRITE>(w, lv + FER_LV_DC16, 16, cavlc_nC(d, s, mb, true, 0, 0));
+        if (i16) cavlc_block_staged<WRITE>(w, lv + FER_LV_DC16, 16, cavlc_nC(d, s, mb, true, 0, 0), st, 64);
         for (int i8 = 0; i8 < 4; i8++)
             if (cbpL & (1 << i8))
                 for (int i4x = 0; i4x < 4; i4x++) {
                     int blk = i8 * 4 + i4x;
-                    cavlc_block<WRITE>(w, lv + blk * 16, i16 ? 15 : 16, cavlc_nC(d, s, mb, true, blk, 0));
+                    cavlc_block_staged<WRITE>(w, lv + blk * 16, i16 ? 15 : 16, cavlc_nC(d, s, mb, true, blk, 0), st, 64);
                 }
         if (cbpC & 3)
-            for (int k = 0; k < 2; k++) cavlc_block<WRITE>(w, lv + FER_LV_CDC + k * 4, 4, -1);
+            for (int k = 0; k < 2; k++) cavlc_block_staged<WRITE>(w, lv + FER_LV_CDC + k * 4, 4, -1, st, 64);
         if (cbpC & 2)
             for (int k = 0; k < 2; k++)
                 for (int b = 0; b < 4; b++)
-                    cavlc_block<WRITE>(w, lv + FER_LV_CAC + (k * 4 + b) * 15, 15, cavlc_nC(d, s, mb, false, b, k));
+                    cavlc_block_staged<WRITE>(w, lv + FER_LV_CAC + (k * 4 + b) * 15, 15, cavlc_nC(d, s, mb, false, b, k), st, 64);
     }
     if (WRITE)
         bw_flush<WRITE>(w);

@@ -209,3 +209,118 @@ __device__ inline void cavlc_block(BitW &w, const int16_t *__restrict__ coef, in
     }
 }
 
+// The same coder for the entropy pass, where one thread codes a whole macroblock: the block's coefficients are
+// staged once in LDS (st[k * stride], one column per thread) and everything else is derived from the bit mask of
+// its non-zero positions, so there are no dependent global loads and no indexed private arrays (scratch).
+template <bool WRITE>
+__device__ inline void cavlc_block_staged(BitW &w, const int16_t *__restrict__ coef, int maxNumCoeff, int nC, int16_t *st,
+                                          int stride)
+{
+    unsigned nz = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int v = i < maxNumCoeff ? coef[i] : 0;
+        st[i * stride] = (int16_t)v;
+        nz |= (v != 0 ? 1u : 0u) << i;
+    }
+    const int TotalCoeff = __popc(nz);
+    int TrailingOnes = 0, total_zeros = 0;
+    if (TotalCoeff) {
+        total_zeros = (32 - __clz((int)nz)) - TotalCoeff;
+        unsigned m = nz;
+        while (m && TrailingOnes < 3) {  // leading run of +-1 from the high-frequency end
+            int i = 31 - __clz((int)m);
+            int v = st[i * stride];
+            if (v != 1 && v != -1) break;
+            TrailingOnes++;
+            m &= ~(1u << i);
+        }
+    }
+    int len;
+    unsigned code;
+    if (nC == -1) {
+        len = c_ctdc_len[TrailingOnes][TotalCoeff];
+        code = c_ctdc_code[TrailingOnes][TotalCoeff];
+    } else if (nC >= 8) {
+        len = 6;
+        code = TotalCoeff == 0 ? 3u : (unsigned)(((TotalCoeff - 1) << 2) | TrailingOnes);
+    } else {
+        int cls = nC <= 1 ? 0 : (nC <= 3 ? 1 : 2);
+        len = c_ct_len[cls][TrailingOnes][TotalCoeff];
+        code = c_ct_code[cls][TrailingOnes][TotalCoeff];
+    }
+    bw_put<WRITE>(w, len, code);
+    if (TotalCoeff == 0) return;
+    int suffixLength = (TotalCoeff > 10 && TrailingOnes < 3) ? 1 : 0;
+    unsigned m = nz;
+    for (int i = 0; i < TotalCoeff; i++) {
+        const int pos = 31 - __clz((int)m);
+        m &= ~(1u << pos);
+        const int lev = st[pos * stride];
+        if (i < TrailingOnes) {
+            bw_put<WRITE>(w, 1, (unsigned)((1 - lev) >> 1));
+        } else {
+            int levelCode = lev < 0 ? -(lev * 2) - 1 : (lev * 2) - 2;
+            if (i == TrailingOnes && TrailingOnes < 3) levelCode -= 2;
+            // level_prefix / level_suffix (closed form of F/residual_tables.cpp:940-1010)
+            int prefix, ss;
+            unsigned suf;
+            if (suffixLength == 0) {
+                if (levelCode < 14) {
+                    prefix = levelCode;
+                    ss = 0;
+                    suf = 0;
+                } else if (levelCode < 30) {
+                    prefix = 14;
+                    ss = 4;
+                    suf = (unsigned)(levelCode - 14);
+                } else {
+                    prefix = 15;
+                    ss = 12;
+                    suf = (unsigned)(levelCode - 30);
+                }
+            } else if (levelCode < (15 << suffixLength)) {
+                prefix = levelCode >> suffixLength;
+                ss = suffixLength;
+                suf = (unsigned)(levelCode & ((1 << suffixLength) - 1));
+            } else {
+                prefix = 15;
+                ss = 12;
+                suf = (unsigned)(levelCode - (15 << suffixLength));
+            }
+            bw_put<WRITE>(w, prefix, 0);
+            bw_put<WRITE>(w, 1, 1);
+            if (suffixLength > 0 || prefix >= 14) bw_put<WRITE>(w, ss, suf);
+            if (suffixLength == 0) suffixLength = 1;
+            if (iabs(lev) > (3 << (suffixLength - 1)) && suffixLength < 6) suffixLength++;
+        }
+    }
+    int zerosLeft = 0;
+    if (TotalCoeff < maxNumCoeff) {
+        if (nC != -1)
+            bw_put<WRITE>(w, c_tz_len[TotalCoeff - 1][total_zeros], c_tz_code[TotalCoeff - 1][total_zeros]);
+        else
+            bw_put<WRITE>(w, c_tzdc_len[TotalCoeff - 1][total_zeros], c_tzdc_code[TotalCoeff - 1][total_zeros]);
+        zerosLeft = total_zeros;
+    }
+    m = nz;
+    for (int j = 0; j < TotalCoeff - 1; j++) {
+        const int pos = 31 - __clz((int)m);
+        m &= ~(1u << pos);
+        const int run = pos - (32 - __clz((int)m));  // zeros between this coefficient and the next lower one
+        if (zerosLeft > 0) {
+            if (zerosLeft > 6) {
+                if (run < 7) {
+                    bw_put<WRITE>(w, 3, (unsigned)(7 - run));
+                } else {
+                    bw_put<WRITE>(w, run - 4, 0);
+                    bw_put<WRITE>(w, 1, 1);
+                }
+            } else {
+                bw_put<WRITE>(w, c_rb_len[zerosLeft - 1][run], c_rb_code[zerosLeft - 1][run]);
+            }
+        }
+        zerosLeft -= run;
+    }
+}
+

@@ -63,8 +63,8 @@ __device__ __forceinline__ void wl_insert(WList &L, int K, int lane, bool valid,
 //   2. the candidates <= T0 are compacted in arrival order (typically 1.2-1.5 x need of them),
 //   3. their exact rank by (metric << 6 | compacted position) places the winners.
 // More than 64 survivors of step 2 or metrics >= 2^26 take the binary-search route instead.
-// v[u] < 0 marks an invalid candidate; pay(u) is the payload (packed vector) of the lane's
-// candidate u.  sel = 256 ints of 16-byte aligned LDS owned by the wavefront.
+// v[u] < 0 marks an invalid candidate; raw(u) is a cheap tag of the lane's candidate u that travels with it,
+// fin(tag) turns the tag of a winner into its packed vector (evaluated once per list slot).  sel = 256 ints of 16-byte aligned LDS owned by the wavefront.
 // sel is private to ONE wavefront: its LDS operations execute in program order, so ordering them needs no
 // s_barrier (which would also be wrong inside the two-wavefront workgroups of k_me_resolve, whose wavefronts
 // call this a different number of times) -- only the compiler must not move them across.
@@ -85,8 +85,8 @@ __device__ __forceinline__ int lds_rank64(const unsigned *p, unsigned mine)
     return r;
 }
 
-template <int NB, class PAY>
-__device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane, int *sel, WList &L, PAY pay)
+template <int NB, class RAW, class FIN>
+__device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane, int *sel, WList &L, RAW raw, FIN fin)
 {
     unsigned *A = (unsigned *)sel, *B = A + 64;
     int *Ci = sel + 128, *Di = sel + 192;
@@ -125,7 +125,7 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
             int pos = c + __popcll(mk & lt);
             if (take && pos < 64) {
                 B[pos] = ((unsigned)v[u] << 6) | (unsigned)pos;
-                Ci[pos] = pay(u);
+                Ci[pos] = raw(u);
             }
             c += __popcll(mk);
         }
@@ -143,7 +143,7 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
         WAVE_LDS_SYNC();
         if (lane < need) {
             L.m = (int)A[lane];
-            L.xy = Di[lane];
+            L.xy = fin(Di[lane]);
         }
         WAVE_LDS_SYNC();
         return;
@@ -183,7 +183,7 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
         if (take) {
             int pos = nsel + __popcll(mt & lt);
             key[pos] = v[u];
-            kxy[pos] = pay(u);
+            kxy[pos] = raw(u);
         }
         nsel += __popcll(mt);
         eq_seen += __popcll(meq);
@@ -202,7 +202,7 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
     WAVE_LDS_SYNC();
     if (lane < need) {
         L.m = key2[lane];
-        L.xy = kxy2[lane];
+        L.xy = fin(kxy2[lane]);
     }
     WAVE_LDS_SYNC();
 }
@@ -366,6 +366,18 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     const int sx = ((mb % d.mbw) << 4) + (part & 1) * 8, sy = ((mb / d.mbw) << 4) + (part >> 1) * 8;
     const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
 
+#ifdef FER_PROBE
+    const bool probe = (d.dbg & 128) && s == 0 && (blockIdx.x % 997) == 5;  // a sample of partitions reports its time split
+    long long tmark = probe ? wall_clock64() : 0;
+#define PP_MARK(k)                                                          \
+    if (probe) {                                                            \
+        long long now_ = wall_clock64();                                    \
+        if (lane == 0) atomicAdd((unsigned long long *)&d.timing[32 + k], (unsigned long long)(now_ - tmark)); \
+        tmark = now_;                                                       \
+    }
+#else
+#define PP_MARK(k)
+#endif
     // box sums of the source block, F/moestimation.cpp:440-451
     int px = lane & 7, py = lane >> 3;
     int v = Y[(size_t)(sy + py) * W + sx + px];
@@ -377,6 +389,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     su[4] = wave_sum((px & 3) > 1 ? 0 : v);
     if (lane < 5) d.suma[pidx * 5 + lane] = su[lane];
     const SuPk sp = su_pack(su);
+    PP_MARK(0)
 
     // source rows for the SAD groups (sx is a multiple of 8: aligned dwords)
     const int row = lane & 7;
@@ -396,6 +409,43 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
         // arrival index (tx outer, ty inner).  Records are fetched six batches at a time with
         // clamped coordinates (no control flow around the loads), then masked.
         constexpr int WCH = 6;
+        if (WIN == 32 || WIN == 16) {
+            // n = WIN + 1: a batch is 64 / WIN rows of the first WIN columns, so the column, its validity and its
+            // weight are per-lane constants and a row step is one address increment; the last column follows
+            constexpr int NBc = WIN ? WIN : 32, RPB = 64 / NBc;
+            const int ix = lane % NBc, r0 = lane / NBc;
+            const int rx = sx - R + ix;
+            const bool xok = rx >= 0 && rx < W;
+            const int wx = iabs(ix - R) + 4;
+            const uint16_t *col = F0 + (size_t)iclamp(rx, 0, W - 1) * 6;
+            for (int iy0 = 0; iy0 < n; iy0 += RPB * WCH) {
+                FeatRec fr[WCH];
+#pragma unroll
+                for (int q = 0; q < WCH; q++) {
+                    int ry = iclamp(sy - R + iy0 + q * RPB + r0, 0, H - 1);
+                    const uint32_t *r = (const uint32_t *)(col + (size_t)ry * W * 6);
+                    fr[q].a = r[0];
+                    fr[q].b = r[1];
+                    fr[q].c = r[2];
+                }
+#pragma unroll
+                for (int q = 0; q < WCH; q++) {
+                    int iy = iy0 + q * RPB + r0;
+                    int ry = sy - R + iy;
+                    int m = (wx + iabs(iy - R)) * feat_dist_w(fr[q].a, fr[q].b, fr[q].c, sp);
+                    if (!(xok && ry >= 0 && ry < H)) m = -1;
+                    if (iy < n) wide_m[ix * n + iy] = m;
+                }
+            }
+            {  // column n - 1
+                const int iy = min(lane, n - 1);
+                const int rxl = sx + R, ry = sy - R + iy;
+                FeatRec f = feat0_load(F0, W, H, ry, rxl);
+                int m = (R + 4 + iabs(iy - R)) * feat_dist_w(f.a, f.b, f.c, sp);
+                if (!(rxl < W && ry >= 0 && ry < H)) m = -1;
+                if (lane < n) wide_m[(n - 1) * n + iy] = m;
+            }
+        } else
         for (int base = 0; base < n * n; base += 64 * WCH) {
             FeatRec fr[WCH];
 #pragma unroll
@@ -416,6 +466,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
             }
         }
         __syncthreads();
+        PP_MARK(1)
         constexpr int LB = 7;  // batches of the local search that ME_SEL_NB leaves room for
         FeatRec fl[LB];
 #pragma unroll
@@ -441,16 +492,16 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
                 if (c < nloc && rx >= 0 && rx < W && ry >= 0 && ry < H) v[u] = m;
             }
         }
-        auto pay = [&](int u) {  // vector of the lane's candidate u
-            if (u < wb) {
-                int c = u * 64 + lane;
-                return pack_xy((c / n - R) * 4, (c % n - R) * 4);
-            }
-            int c = (u - wb) * 64 + lane;
+        auto raw = [&](int u) { return u * 64 + lane; };  // arrival index
+        auto fin = [&](int idx) {                          // ... to the candidate's vector
+            if (idx < wb * 64) return pack_xy((idx / n - R) * 4, (idx % n - R) * 4);
+            int c = idx - wb * 64;
             int frac = c & 15, pos = c >> 4;
             return pack_xy((pos / n2w - r2) * 4 + (frac & 3), (pos % n2w - r2) * 4 + (frac >> 2));
         };
-        select_topk<ME_SEL_NB>(v, 33, lane, sel_lds, L, pay);
+        PP_MARK(2)
+        select_topk<ME_SEL_NB>(v, 33, lane, sel_lds, L, raw, fin);
+        PP_MARK(3)
     } else {
         for (int base = 0; base < n * n && !(d.dbg & 1); base += 64) {
             int c = base + lane;
@@ -595,7 +646,7 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
             uint32_t e12 = pk_abs16(pk_sub16(r1, sp.s12));
             bool ok = lane < b_cnt && dist < 280u && (pk_sub16(e12, 0x00640064u) & 0x80008000u) == 0x80008000u;
             unsigned long long mk = __ballot(ok);
-            int rank = tren + __popcll(mk & ltm);
+            int rank = tren + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
             // feature distance from the sorted payload (kar0 == a): |s0-a| + sum |si-qi| + sum |(s0-si) - (a-qi)|
             uint32_t aa = (uint32_t)a | ((uint32_t)a << 16);
             uint32_t D = __builtin_amdgcn_sad_u16(r1, sp.s12, (uint32_t)iabs(su[0] - a));
@@ -843,8 +894,8 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
     L1.m = INF_M;
     L1.xy = 0;
     const int r1 = window / 16, n1 = 2 * r1 + 1, tot1 = (d.dbg & 16) ? 0 : n1 * n1 * 16;
-    auto pay1 = [&](int u) {
-        int cc = u * 64 + lane;
+    auto raw1 = [&](int u) { return u * 64 + lane; };  // arrival index
+    auto fin1 = [&](int cc) {
         int frac = cc & 15, pos = cc >> 4;
         return pack_xy((genx - r1 + pos / n1) * 4 + (frac & 3), (geny - r1 + pos % n1) * 4 + (frac >> 2));
     };
@@ -867,7 +918,7 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
             int mm = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist_w(fr[u].a, fr[u].b, fr[u].c, sp);
             m[u] = ok ? mm : -1;
         }
-        select_topk<ST1_UNROLL>(m, 17, lane, sel_lds, L1, pay1);
+        select_topk<ST1_UNROLL>(m, 17, lane, sel_lds, L1, raw1, fin1);
     } else {
         for (int base = 0; base < tot1; base += 64) {
             int cc = base + lane;
@@ -910,9 +961,10 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
         int tx = P.e2[u].x >> 16, ty = (int)(short)(P.e2[u].x & 0xffff);  // k_me_walk stores (tx << 16) | (ty & 0xffff)
         m2[u] = cc < P.n2 ? (iabs(tx - genx) + iabs(ty - geny) + 4) * P.e2[u].y : -1;
     }
-    auto pay2 = [&](int u) { return pack_xy((P.e2[u].x >> 16) * 4, (int)(short)(P.e2[u].x & 0xffff) * 4); };
+    auto raw2 = [&](int u) { return P.e2[u].x; };
+    auto fin2 = [&](int e) { return pack_xy((e >> 16) * 4, (int)(short)(e & 0xffff) * 4); };
     WList L2;
-    select_topk<FER_ST2_CAP / 64>(m2, 33, lane, sel_lds, L2, pay2);
+    select_topk<FER_ST2_CAP / 64>(m2, 33, lane, sel_lds, L2, raw2, fin2);
     const int cnt2 = __popcll(__ballot(lane < 33 && L2.m < 100000000));
     int b2, b2xy;
     sad_keys<33>(L2, cnt2, lane, Ps, ysz, W, H, sx, sy, P.src0, P.src1, mvpx, mvpy, b2, b2xy);

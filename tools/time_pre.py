@@ -20,4 +20,9 @@ if int(os.environ.get("FER_DBG", "0")) & 128:  # needs a build with EXTRA=-DFER_
         n = max(int(r[7]), 1)
         print("probe row, wavefront %d, us per partition: " % role + "  ".join(
             "%s %.2f" % (nm, r[k] / n / 100) for k, nm in enumerate(["prefetch+poll", "stage", "barrier1", "merge+publish", "barrier2"])))
+if int(os.environ.get("FER_DBG", "0")) & 128:
+    t = g.read("TIMING")
+    n = max(int(t[39]), 1)
+    print("k_me_pre sample of %d partitions, us each: " % n + "  ".join(
+        "%s %.2f" % (nm, t[32 + k] / n / 100) for k, nm in enumerate(["sums", "wide", "local", "select", "sads"])))
 print(os.environ.get("FER_DBG", "0"), {k: round(v[0] / 3, 2) for k, v in g.get_profile().items() if v[0] > 0})
