@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("FER_BENCH_STREAMS", "64")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("FER_BENCH_STREAMS", "128")))
     ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("FER_BENCH_STAGGER_MS", "0")),
                     help="start offset between consecutive contexts (milliseconds)")
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("FER_BENCH_CONTEXTS", "2")),
@@ -159,34 +159,44 @@ def main():
     total_mbs = world * S * GOP * nmb * args.steps
     value = total_mbs / dt
 
-    # roofline of the dominant kernel (by accumulated device time)
-    dom = max(("me_pre", "me_resolve", "intra", "refprep", "cavlc", "p_resid"), key=lambda k: prof[k][0])
-    ms, launches = prof[dom]
+    # roofline of the dominant kernel (by accumulated device time; every profiled phase is one kernel, except
+    # "sort" = k_sort_keys + radix sort + k_sort_finish and "cavlc" = size + scan + emit)
     p_pictures = (GOP - 1) * args.steps
-    # accumulated over contexts: `launches` counts every context's launches, units all streams
-    units = {"me_pre": S * nmb * p_pictures, "me_resolve": S * nmb * p_pictures, "p_resid": S * nmb * p_pictures,
-             "refprep": S * nmb * p_pictures, "intra": S * nmb * args.steps,
-             "cavlc": S * nmb * GOP * args.steps}[dom]
-    bytes_per_mb = {"me_pre": ME_BYTES_PER_MB, "me_resolve": ME_BYTES_PER_MB, "p_resid": 1152, "refprep": 384 + 16 * 256,
-                    "intra": 768, "cavlc": 800}[dom]
-    # HBM traffic per launch from the committed PMC measurement (profiles/r01_traffic.json), scaled to the
-    # macroblocks one launch processes here; None when the file is absent
-    traffic = None
+    KERNELS = {  # phase -> (kernel, algorithmic bytes per macroblock, pictures it runs on)
+        "interp": ("k_interp", 256 + 16 * 256, p_pictures),
+        "features": ("k_features", 16 * 256 + 256 * (192 + 12), p_pictures),
+        "sort": ("k_sort_keys+radix_sort+k_sort_finish", 256 * (2 + 8) + 3 * 256 * 16 + 256 * (8 + 12 + 16), p_pictures),
+        "me_pre": ("k_me_pre", ME_BYTES_PER_MB, p_pictures),
+        "me_walk": ("k_me_walk", ME_BYTES_PER_MB, p_pictures),
+        "me_resolve": ("k_me_resolve", ME_BYTES_PER_MB, p_pictures),
+        "p_resid": ("k_p_resid", 1152, p_pictures),
+        "intra": ("k_intra_mb", 768, args.steps),
+        "cavlc": ("k_cavlc", 800, GOP * args.steps),
+    }
+    # HBM traffic per macroblock from the committed PMC measurement (profiles/r01_traffic.json); None when absent
+    per_mb_traffic = {}
     tj = ROOT / "profiles" / "r01_traffic.json"
     if tj.exists():
-        per_mb = json.loads(tj.read_text())["bytes_per_mb"].get(dom)
-        if per_mb:
-            traffic = round(per_mb * units / max(launches, 1))
-    avg_launch_s = (ms / 1e3) / max(launches, 1)
-    achieved = (bytes_per_mb * units / max(launches, 1)) / avg_launch_s / 1e9 if ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": {"me_pre": "k_me_pre", "me_resolve": "k_me_resolve", "intra": "k_intra_mb",
-                                           "refprep": "k_interp+k_features+sort", "cavlc": "k_cavlc",
-                                           "p_resid": "k_p_resid"}[dom],
-                "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches": launches,
-                "bytes_per_mb": bytes_per_mb,
-                "phase_ms": {k: round(v[0], 2) for k, v in prof.items()}}
+        per_mb_traffic = json.loads(tj.read_text()).get("bytes_per_mb", {})
+
+    def line(k):
+        name, bpm, pics = KERNELS[k]
+        ms_, launches_ = prof[k]
+        units = S * nmb * pics  # accumulated over contexts, like ms_ and launches_
+        per_launch_s = (ms_ / 1e3) / max(launches_, 1)
+        ach = (bpm * units / max(launches_, 1)) / per_launch_s / 1e9 if ms_ > 0 else 0.0
+        tr = per_mb_traffic.get(k)
+        return {"kernel": name, "achieved": round(ach, 3), "frac": round(ach / HBM_PEAK_GBS, 6),
+                "traffic": round(tr * units / max(launches_, 1)) if tr else None,
+                "avg_launch_us": round(per_launch_s * 1e6, 2), "launches": launches_, "bytes_per_mb": bpm,
+                "total_ms": round(ms_, 2)}
+
+    dom = max(KERNELS, key=lambda k: prof[k][0])
+    dl = line(dom)
+    roofline = {"bound": "hbm", "kernel": dl["kernel"], "achieved": dl["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dl["frac"], "traffic": dl["traffic"], "avg_launch_us": dl["avg_launch_us"],
+                "launches": dl["launches"], "bytes_per_mb": dl["bytes_per_mb"],
+                "kernels": {k: line(k) for k in KERNELS}}
 
     out = None
     if rank == 0:

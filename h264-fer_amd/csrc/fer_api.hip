@@ -514,12 +514,26 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
     const int ndiag = d.mbw + 2 * (d.mbh - 1);
     if (anyP) {
         if (!c->refprep_valid) {
-            ProfScope ps(c, FERHIP_PH_REFPREP, 1);
-            fer_launch_refprep(d, c->sort, c->types.data(), c->st);
+            {
+                ProfScope ps(c, FERHIP_PH_INTERP, 1);
+                fer_launch_interp(d, c->st);
+            }
+            {
+                ProfScope ps(c, FERHIP_PH_FEATURES, 1);
+                fer_launch_features(d, c->st);
+            }
+            {
+                ProfScope ps(c, FERHIP_PH_SORT, 1);
+                fer_launch_sort(d, c->sort, c->st);
+            }
         }
         {
             ProfScope ps(c, FERHIP_PH_ME_PRE, 1);
             fer_launch_me_pre(d, c->st);
+        }
+        {
+            ProfScope ps(c, FERHIP_PH_ME_WALK, 1);
+            fer_launch_me_walk(d, c->st);
         }
         {
             // the per-diagonal chain is latency bound: run it on the high-priority stream so that its small
@@ -535,8 +549,7 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
             CK(hipStreamWaitEvent(c->st, c->ev_b, 0));
         }
         {
-            ProfScope ps(c, FERHIP_PH_P_RESID, 2);
-            fer_launch_me_finish(d, c->st);
+            ProfScope ps(c, FERHIP_PH_P_RESID, 1);
             fer_launch_p_resid(d, c->st);
         }
     }
@@ -727,11 +740,15 @@ extern "C" int ferhip_inter_encoding(ferhip_ctx *c)
         fer_launch_me_pre(c->d, c->st);
     }
     {
+        ProfScope ps(c, FERHIP_PH_ME_WALK, 1);
+        fer_launch_me_walk(c->d, c->st);
+    }
+    {
         ProfScope ps(c, FERHIP_PH_ME_RESOLVE, fer_me_resolve_launches(c->d));
         c->d.serial = c->d.serial % 0x7ffffff0 + 1;
         fer_launch_me_resolve(c->d, c->st);
     }
-    fer_launch_me_finish(c->d, c->st);
+    fer_launch_p_resid(c->d, c->st);  // partition merge + mvd share the residual wavefront of the macroblock
     CK(hipStreamSynchronize(c->st));
     CK(hipGetLastError());
     return 0;

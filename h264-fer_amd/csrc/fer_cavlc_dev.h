@@ -107,111 +107,23 @@ __device__ inline int cavlc_nC(const FerDev &d, int s, int mb, bool luma, int bl
     return 0;
 }
 
-// residual_block_cavlc_write / _size, F/residual.cpp:374-666 / :673-957
+// residual_block_cavlc_write / _size, F/residual.cpp:374-666 / :673-957.  Everything is derived from the bit mask
+// of the non-zero positions; coefficients are read back by index from st[k * stride] (LDS), so there are no
+// indexed private arrays (scratch) and no chains of dependent loads.
 template <bool WRITE>
-__device__ inline void cavlc_block(BitW &w, const int16_t *__restrict__ coef, int maxNumCoeff, int nC)
-{
-    int level[16], run[16];
-    int TotalCoeff = 0, TrailingOnes = 0, total_zeros = 0;
-    bool only_ones = true;
-    for (int i = maxNumCoeff - 1; i >= 0; i--) {
-        int v = coef[i];
-        if (v != 0) {
-            int r = 0;
-            for (int j = i - 1; j >= 0 && coef[j] == 0; j--) r++;
-            run[TotalCoeff] = r;
-            if ((v == 1 || v == -1) && TrailingOnes < 3 && only_ones)
-                TrailingOnes++;
-            else
-                only_ones = false;
-            level[TotalCoeff++] = v;
-        } else if (TotalCoeff > 0) {
-            total_zeros++;
-        }
-    }
-    int len;
-    unsigned code;
-    if (nC == -1) {
-        len = c_ctdc_len[TrailingOnes][TotalCoeff];
-        code = c_ctdc_code[TrailingOnes][TotalCoeff];
-    } else if (nC >= 8) {
-        len = 6;
-        code = TotalCoeff == 0 ? 3u : (unsigned)(((TotalCoeff - 1) << 2) | TrailingOnes);
-    } else {
-        int cls = nC <= 1 ? 0 : (nC <= 3 ? 1 : 2);
-        len = c_ct_len[cls][TrailingOnes][TotalCoeff];
-        code = c_ct_code[cls][TrailingOnes][TotalCoeff];
-    }
-    bw_put<WRITE>(w, len, code);
-    if (TotalCoeff == 0) return;
-    int suffixLength = (TotalCoeff > 10 && TrailingOnes < 3) ? 1 : 0;
-    for (int i = 0; i < TotalCoeff; i++) {
-        if (i < TrailingOnes) {
-            bw_put<WRITE>(w, 1, (unsigned)((1 - level[i]) >> 1));
-        } else {
-            int levelCode = level[i] < 0 ? -(level[i] * 2) - 1 : (level[i] * 2) - 2;
-            if (i == TrailingOnes && TrailingOnes < 3) levelCode -= 2;
-            // level_prefix / level_suffix (closed form of F/residual_tables.cpp:940-1010)
-            int prefix, ss;
-            unsigned suf;
-            if (suffixLength == 0) {
-                if (levelCode < 14) {
-                    prefix = levelCode;
-                    ss = 0;
-                    suf = 0;
-                } else if (levelCode < 30) {
-                    prefix = 14;
-                    ss = 4;
-                    suf = (unsigned)(levelCode - 14);
-                } else {
-                    prefix = 15;
-                    ss = 12;
-                    suf = (unsigned)(levelCode - 30);
-                }
-            } else if (levelCode < (15 << suffixLength)) {
-                prefix = levelCode >> suffixLength;
-                ss = suffixLength;
-                suf = (unsigned)(levelCode & ((1 << suffixLength) - 1));
-            } else {
-                prefix = 15;
-                ss = 12;
-                suf = (unsigned)(levelCode - (15 << suffixLength));
-            }
-            bw_put<WRITE>(w, prefix, 0);
-            bw_put<WRITE>(w, 1, 1);
-            if (suffixLength > 0 || prefix >= 14) bw_put<WRITE>(w, ss, suf);
-            if (suffixLength == 0) suffixLength = 1;
-            if (iabs(level[i]) > (3 << (suffixLength - 1)) && suffixLength < 6) suffixLength++;
-        }
-    }
-    int zerosLeft = 0;
-    if (TotalCoeff < maxNumCoeff) {
-        if (nC != -1)
-            bw_put<WRITE>(w, c_tz_len[TotalCoeff - 1][total_zeros], c_tz_code[TotalCoeff - 1][total_zeros]);
-        else
-            bw_put<WRITE>(w, c_tzdc_len[TotalCoeff - 1][total_zeros], c_tzdc_code[TotalCoeff - 1][total_zeros]);
-        zerosLeft = total_zeros;
-    }
-    for (int j = 0; j < TotalCoeff - 1; j++) {
-        if (zerosLeft > 0) {
-            if (zerosLeft > 6) {
-                if (run[j] < 7) {
-                    bw_put<WRITE>(w, 3, (unsigned)(7 - run[j]));
-                } else {
-                    bw_put<WRITE>(w, run[j] - 4, 0);
-                    bw_put<WRITE>(w, 1, 1);
-                }
-            } else {
-                bw_put<WRITE>(w, c_rb_len[zerosLeft - 1][run[j]], c_rb_code[zerosLeft - 1][run[j]]);
-            }
-        }
-        zerosLeft -= run[j];
-    }
-}
+__device__ inline void cavlc_block_core(BitW &w, unsigned nz, int maxNumCoeff, int nC, const int16_t *st, int stride);
 
-// The same coder for the entropy pass, where one thread codes a whole macroblock: the block's coefficients are
-// staged once in LDS (st[k * stride], one column per thread) and everything else is derived from the bit mask of
-// its non-zero positions, so there are no dependent global loads and no indexed private arrays (scratch).
+// coefficients already in LDS, contiguous
+template <bool WRITE>
+__device__ inline void cavlc_block(BitW &w, const int16_t *coef, int maxNumCoeff, int nC)
+{
+    unsigned nz = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) nz |= (i < maxNumCoeff && coef[i] != 0 ? 1u : 0u) << i;
+    cavlc_block_core<WRITE>(w, nz, maxNumCoeff, nC, coef, 1);
+}
+// coefficients in global memory (the entropy pass, one thread per macroblock): staged once in LDS,
+// one column per thread
 template <bool WRITE>
 __device__ inline void cavlc_block_staged(BitW &w, const int16_t *__restrict__ coef, int maxNumCoeff, int nC, int16_t *st,
                                           int stride)
@@ -223,6 +135,12 @@ __device__ inline void cavlc_block_staged(BitW &w, const int16_t *__restrict__ c
         st[i * stride] = (int16_t)v;
         nz |= (v != 0 ? 1u : 0u) << i;
     }
+    cavlc_block_core<WRITE>(w, nz, maxNumCoeff, nC, st, stride);
+}
+
+template <bool WRITE>
+__device__ inline void cavlc_block_core(BitW &w, unsigned nz, int maxNumCoeff, int nC, const int16_t *st, int stride)
+{
     const int TotalCoeff = __popc(nz);
     int TrailingOnes = 0, total_zeros = 0;
     if (TotalCoeff) {

@@ -11,10 +11,13 @@ struct FerSortTmp {
 
 size_t fer_sort_tmp_bytes(int n, int S);
 void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStream_t st);
+void fer_launch_interp(const FerDev &d, hipStream_t st);
+void fer_launch_features(const FerDev &d, hipStream_t st);
+void fer_launch_sort(const FerDev &d, FerSortTmp &t, hipStream_t st);
+void fer_launch_me_walk(const FerDev &d, hipStream_t st);
 void fer_launch_frame_sad(const FerDev &d, hipStream_t st);
 void fer_launch_me_pre(const FerDev &d, hipStream_t st);
 void fer_launch_me_resolve(const FerDev &d, hipStream_t st);
-void fer_launch_me_finish(const FerDev &d, hipStream_t st);
 int fer_me_resolve_launches(const FerDev &d);
 void fer_launch_p_resid(const FerDev &d, hipStream_t st);
 void fer_launch_intra(const FerDev &d, hipStream_t st);

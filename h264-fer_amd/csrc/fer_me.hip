@@ -749,7 +749,7 @@ __device__ __forceinline__ void take_best(int best, int bestxy, int &bmin, int &
 // the precomputed stage-2 set (top 33, their SADs) and the stage-3 survivors.  Both read the
 // neighbour vectors themselves; they meet twice per partition through LDS.
 // Everything after the vector of the partition is known (merge, mvd, final prediction,
-// snapping) is not on any other partition's dependency chain and lives in k_me_finish.
+// snapping) is not on any other partition's dependency chain and lives in k_p_resid (fer_resid.hip).
 #define ST1_UNROLL 7
 #define RES_SPIN_LIMIT (1 << 23)
 
@@ -1018,14 +1018,18 @@ __global__ __launch_bounds__(128, 2) void k_me_resolve(FerDev d)
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int *sel_lds = sel_all[role];
     const int gw = d.mbw * 2, gh = d.mbh * 2;
-    // row ticket: rows of all streams in row-major order
+    // Row tickets: rows of all streams in row-major order.  The launch is capped at a share of the GPU's
+    // workgroup slots (other contexts' kernels keep finding free slots); a workgroup that finishes a row takes
+    // the next ticket.
+    for (;;) {
+    __syncthreads();
     if (threadIdx.x == 0) xch[0] = atomicAdd(d.chain, 1);
     __syncthreads();
     const int t = xch[0];
     __syncthreads();
     const int gy = t / d.S, s = t - gy * d.S;
     if (gy >= gh) return;
-    if (d.hdr[s * 4 + 3] != 0) return;  // not a P picture: nobody waits on these rows
+    if (d.hdr[s * 4 + 3] != 0) continue;  // not a P picture: nobody waits on these rows
     unsigned long long *chw = d.chain64 + (size_t)s * d.nmb * 4;
     int *mbt = d.mb_type + (size_t)s * d.nmb;
     short *mvs = d.mv + (size_t)s * d.nmb * 8;
@@ -1168,105 +1172,7 @@ __global__ __launch_bounds__(128, 2) void k_me_resolve(FerDev d)
     }
 #undef PR_MARK
     if (timeout && lane == 0) atomicOr(&d.status[s], FER_ERR_CHAIN_TIMEOUT);
-}
-
-// ------------------------------------------------------------------ k_me_finish
-// After every partition vector of the picture is final: partition merge, mvd, final motion
-// compensation and source snapping of one macroblock per wavefront (F/moestimation.cpp:529-584).
-// Nothing in here is read by another macroblock's decision, so all macroblocks run in parallel.
-__global__ __launch_bounds__(64) void k_me_finish(FerDev d)
-{
-    const int lane = threadIdx.x;
-    const int s = blockIdx.y, mb = blockIdx.x;
-    if (d.hdr[s * 4 + 3] != 0) return;
-    int *mbt = d.mb_type + (size_t)s * d.nmb;
-    if (mbt[mb] == FER_P_SKIP) return;
-    const int mbx = mb % d.mbw, mby = mb / d.mbw;
-    const int W = d.W, H = d.H, Wc = d.Wc, Hc = d.Hc;
-    const size_t ysz = d.ysz, csz = d.csz;
-    uint8_t *Y = d.curY + (size_t)s * ysz;
-    uint8_t *Cb = d.curCb + (size_t)s * csz, *Cr = d.curCr + (size_t)s * csz;
-    const uint8_t *RY = d.refY + (size_t)s * ysz;
-    const uint8_t *RCb = d.refCb + (size_t)s * csz, *RCr = d.refCr + (size_t)s * csz;
-    const uint8_t *Ps = d.interp + (size_t)s * 16 * ysz;
-    const short *mvs = d.mv + (size_t)s * d.nmb * 8;
-    const int xp = mbx << 4, yp = mby << 4;
-    const int lx = (lane & 3) * 4, ly = lane >> 2;
-    const int cxl = lane & 7, cyl = lane >> 3;
-
-    int mvx[4], mvy[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        mvx[i] = mvs[(mb * 4 + i) * 2];
-        mvy[i] = mvs[(mb * 4 + i) * 2 + 1];
     }
-    int type = FER_P_8x8ref0, stat = 4;
-    if (mvx[0] == mvx[1] && mvx[0] == mvx[2] && mvx[0] == mvx[3] && mvy[0] == mvy[1] && mvy[0] == mvy[2] &&
-        mvy[0] == mvy[3]) {
-        type = FER_P_L0_16x16;
-        stat = 1;
-    } else if (mvx[0] == mvx[1] && mvx[2] == mvx[3] && mvy[0] == mvy[1] && mvy[2] == mvy[3]) {
-        type = FER_P_16x8;
-        stat = 2;
-    } else if (mvx[0] == mvx[2] && mvx[1] == mvx[3] && mvy[0] == mvy[2] && mvy[1] == mvy[3]) {
-        type = FER_P_8x16;
-        stat = 3;
-    }
-    // mvd under the final type (own earlier partitions are read from d.mv like the neighbours)
-    MvCtx c;
-    c.mv = mvs;
-    c.mb_type = nullptr;
-    c.mbw = d.mbw;
-    c.cur = mb;
-    c.type = type;
-    c.coh = false;
-    int np = type == FER_P_L0_16x16 ? 1 : (type == FER_P_8x8ref0 ? 4 : 2);
-    int dvx[4] = {0, 0, 0, 0}, dvy[4] = {0, 0, 0, 0};
-    for (int i = 0; i < np; i++) {
-        int q = (type == FER_P_16x8 && i == 1) ? 2 : i;  // quadrant that carries partition i's vector
-        int px_, py_;
-        predict_luma(c, i, px_, py_);
-        dvx[i] = mvx[q] - px_;
-        dvy[i] = mvy[q] - py_;
-    }
-    if (lane < 4) {
-        short *o = d.mvd + ((size_t)s * d.nmb + mb) * 8;
-        o[lane * 2] = (short)dvx[lane];
-        o[lane * 2 + 1] = (short)dvy[lane];
-    }
-    if (lane == 0) {
-        mbt[mb] = type;
-        atomicAdd(&d.stats[s * 5 + stat], 1);
-    }
-    int srcv[4];
-    uint32_t sv = *(const uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx);
-#pragma unroll
-    for (int k = 0; k < 4; k++) srcv[k] = (sv >> (8 * k)) & 0xff;
-    int MAXDIFF = d.maxdiff_set;
-    if (d.maxdiff_set == -1) {
-        int mean = wave_sum(srcv[0] + srcv[1] + srcv[2] + srcv[3]) / 256;
-        int dev = wave_sum(iabs(srcv[0] - mean) + iabs(srcv[1] - mean) + iabs(srcv[2] - mean) + iabs(srcv[3] - mean));
-        MAXDIFF = dev / 256;
-        if (MAXDIFF < 3) MAXDIFF = 3;
-    }
-    int q = (ly >> 3) * 2 + (lx >> 3);
-    int pf[4];
-    mc_luma4(RY, Ps, ysz, W, H, xp, yp, lx, ly, mvx[q], mvy[q], pf);
-    uint32_t packed = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) packed |= (uint32_t)(iabs(srcv[k] - pf[k]) < MAXDIFF ? pf[k] : srcv[k]) << (8 * k);
-    *(uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx) = packed;
-    int qc = (cyl >> 2) * 2 + (cxl >> 2);
-    size_t co = (size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl;
-    int pb = mc_chroma(RCb, Wc, Hc, xp / 2, yp / 2, cxl, cyl, mvx[qc], mvy[qc]);
-    int pr = mc_chroma(RCr, Wc, Hc, xp / 2, yp / 2, cxl, cyl, mvx[qc], mvy[qc]);
-    if (iabs((int)Cb[co] - pb) <= MAXDIFF) Cb[co] = (uint8_t)pb;
-    if (iabs((int)Cr[co] - pr) <= MAXDIFF) Cr[co] = (uint8_t)pr;
-}
-
-void fer_launch_me_finish(const FerDev &d, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_me_finish, dim3(d.nmb, d.S), dim3(64), 0, st, d);
 }
 
 void fer_launch_me_pre(const FerDev &d, hipStream_t st)
@@ -1278,7 +1184,11 @@ void fer_launch_me_pre(const FerDev &d, hipStream_t st)
         hipLaunchKernelGGL(k_me_pre<16>, g, dim3(64), 0, st, d);
     else
         hipLaunchKernelGGL(k_me_pre<0>, g, dim3(64), 0, st, d);
-    hipLaunchKernelGGL(k_me_walk, g, dim3(64), 0, st, d);
+}
+
+void fer_launch_me_walk(const FerDev &d, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_me_walk, dim3(d.nmb * 4, d.S), dim3(64), 0, st, d);
 }
 
 int fer_me_resolve_launches(const FerDev &d)
@@ -1291,7 +1201,8 @@ void fer_launch_me_resolve(const FerDev &d, hipStream_t st)
 {
     const int gh = 2 * d.mbh;
     hipMemsetAsync(d.chain, 0, sizeof(int), st);
-    dim3 g(gh * d.S);
+    static const int cap = getenv("FER_RESOLVE_WGS") ? atoi(getenv("FER_RESOLVE_WGS")) : 1536;
+    dim3 g(min(gh * d.S, max(cap, 1)));
     if (d.window == 32)
         hipLaunchKernelGGL(k_me_resolve<32>, g, dim3(128), 0, st, d);
     else if (d.window == 16)

@@ -8,7 +8,6 @@
 #include <cstring>
 #include <string.h>
 #include "fer_internal.h"
-#include <rocprim/rocprim.hpp>
 
 // ------------------------------------------------------------------ k_interp
 // block = 64x4 threads, each thread one pixel; LDS tile (64+5) x (4+5) of the clamped reference.
@@ -178,14 +177,10 @@ __global__ void k_sort_keys(FerDev d, uint32_t *keys, uint32_t *vals)
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     int n = d.W * d.H;
     if (b >= n) return;
-    if (d.hdr[s * 4 + 3] != 0) {  // not a P picture: keep the segment populated so the device-wide order stays aligned
-        keys[(size_t)s * n + b] = (uint32_t)s << 15;
-        vals[(size_t)s * n + b] = 0;
-        return;
-    }
+    if (d.hdr[s * 4 + 3] != 0) return;
     int tx = b / d.H, ty = b % d.H;
     uint16_t k = d.feat0[((size_t)s * d.ysz + (size_t)ty * d.W + tx) * 6];
-    keys[(size_t)s * n + b] = ((uint32_t)s << 15) | k;  // one device-wide sort: stream id above the 15-bit sum
+    keys[(size_t)s * n + b] = k;
     vals[(size_t)s * n + b] = ((uint32_t)tx << 16) | (uint32_t)ty;
     if (k == 0) atomicOr(&d.status[s], FER_ERR_ZERO_SUM);  // the reference mis-files sum 0 (F/moestimation.cpp:153)
 }
@@ -246,35 +241,179 @@ __global__ __launch_bounds__(256) void k_sort_finish(FerDev d, const uint32_t *s
     }
 }
 
-static int sort_end_bit(int S)
+// ---- stable LSD radix sort of one stream's (sum, position) pairs: two passes of 8 + 7 bits ----
+// The order the reference's counting sort produces (F/moestimation.cpp:140-172) is "by sum, ties in arrival
+// order", i.e. a stable sort of the arrival sequence.  Each pass is three launches -- per-tile digit
+// histograms, one exclusive scan per stream over (digit, tile), stable scatter -- and no block ever waits on
+// another one, so the sort keeps its speed when another context's kernels share the GPU (a single-pass
+// look-back sort stalls there).  Streams are independent segments (blockIdx.y).
+#define RS_THREADS 256
+#define RS_ITEMS 16
+#define RS_TILE (RS_THREADS * RS_ITEMS)
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(FerDev d, const uint32_t *keys, uint32_t *hist, int ntiles, int shift)
 {
-    int b = 15;
-    while ((1 << (b - 15)) < S) b++;
-    return b;
+    __shared__ unsigned h[256];
+    const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    if (d.hdr[s * 4 + 3] != 0) return;
+    const int n = d.W * d.H;
+    keys += (size_t)s * n;
+    h[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        int idx = tile * RS_TILE + i * RS_THREADS + tid;
+        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    hist[((size_t)s * 256 + tid) * ntiles + tile] = h[tid];  // digit-major: the scan order is the output order
+}
+
+__global__ __launch_bounds__(1024) void k_rs_scan(FerDev d, uint32_t *hist, int ntiles)
+{
+    __shared__ unsigned part[1024];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (d.hdr[s * 4 + 3] != 0) return;
+    uint32_t *h = hist + (size_t)s * 256 * ntiles;
+    const int n = 256 * ntiles;
+    const int per = (n + 1023) / 1024;
+    const int b0 = min(tid * per, n), b1 = min(b0 + per, n);
+    unsigned sum = 0;
+    for (int i = b0; i < b1; i++) sum += h[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        unsigned v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = tid ? part[tid - 1] : 0;
+    for (int i = b0; i < b1; i++) {
+        unsigned v = h[i];
+        h[i] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint32_t *keys_in, const uint32_t *vals_in,
+                                                          uint32_t *keys_out, uint32_t *vals_out, const uint32_t *hist,
+                                                          int ntiles, int shift)
+{
+    __shared__ unsigned run[RS_THREADS / 64][256];  // per wavefront: items of each digit seen so far
+    __shared__ unsigned base[256];
+    const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    if (d.hdr[s * 4 + 3] != 0) return;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int n = d.W * d.H;
+    keys_in += (size_t)s * n;
+    vals_in += (size_t)s * n;
+    keys_out += (size_t)s * n;
+    vals_out += (size_t)s * n;
+#pragma unroll
+    for (int w = 0; w < RS_THREADS / 64; w++) run[w][tid] = 0;
+    base[tid] = hist[((size_t)s * 256 + tid) * ntiles + tile];
+    __syncthreads();
+    // a wavefront owns a contiguous quarter of the tile and walks it in arrival order, 64 items per round
+    const int w0 = tile * RS_TILE + wv * (RS_TILE / (RS_THREADS / 64));
+    uint32_t key[RS_ITEMS], val[RS_ITEMS];
+    unsigned rk[RS_ITEMS];  // rank among the wavefront's earlier items of the same digit
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        int idx = w0 + r * 64 + lane;
+        bool ok = idx < n;
+        key[r] = ok ? keys_in[idx] : 0xffffffffu;
+        val[r] = ok ? vals_in[idx] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const bool ok = w0 + r * 64 + lane < n;
+        const unsigned dg = (key[r] >> shift) & 0xff;
+        unsigned long long peers = __ballot(ok);  // lanes with the same digit
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            unsigned long long bal = __ballot((dg >> b) & 1);
+            peers &= ((dg >> b) & 1) ? bal : ~bal;
+        }
+        const unsigned before = run[wv][dg];
+        rk[r] = before + (unsigned)__popcll(peers & lt);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (ok && (peers & lt) == 0) run[wv][dg] = before + (unsigned)__popcll(peers);  // first lane of the group
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {  // digit tid: turn the wavefront totals into offsets behind the tile's base
+        unsigned acc = base[tid];
+#pragma unroll
+        for (int w = 0; w < RS_THREADS / 64; w++) {
+            unsigned c = run[w][tid];
+            run[w][tid] = acc;
+            acc += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        if (w0 + r * 64 + lane < n) {
+            const unsigned dg = (key[r] >> shift) & 0xff;
+            const unsigned pos = run[wv][dg] + rk[r];
+            keys_out[pos] = key[r];
+            vals_out[pos] = val[r];
+        }
+    }
 }
 
 size_t fer_sort_tmp_bytes(int n, int S)
 {
-    size_t bytes = 0;
-    rocprim::radix_sort_pairs((void *)nullptr, bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                              (uint32_t *)nullptr, (size_t)n * S, 0, sort_end_bit(S), (hipStream_t)0);
-    return bytes;
+    const int ntiles = (n + RS_TILE - 1) / RS_TILE;
+    return (size_t)S * 256 * ntiles * sizeof(uint32_t);
 }
 
-// host side: prepare the reference structures of all P-picture streams
+// host side: prepare the reference structures of all P-picture streams (three profiled steps)
+void fer_launch_interp(const FerDev &d, hipStream_t st)
+{
+    dim3 gi((d.W + IT_W - 1) / IT_W, (d.H + IT_H - 1) / IT_H, d.S);
+    hipLaunchKernelGGL(k_interp, gi, dim3(IT_W, IT_H), 0, st, d);
+}
+
+void fer_launch_features(const FerDev &d, hipStream_t st)
+{
+    long long fw = (long long)(d.W >> 2) * ((d.H + FS_ROWS - 1) / FS_ROWS) * d.S;
+    hipLaunchKernelGGL(k_features, dim3((unsigned)((fw + 3) / 4)), dim3(256), 0, st, d);
+}
+
+void fer_launch_sort(const FerDev &d, FerSortTmp &t, hipStream_t st)
+{
+    int n = d.W * d.H;
+    hipLaunchKernelGGL(k_sort_keys, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.keys_in, t.vals_in);
+    const int ntiles = (n + RS_TILE - 1) / RS_TILE;
+    uint32_t *hist = (uint32_t *)t.tmp;
+    uint32_t *ki = t.keys_in, *vi = t.vals_in, *ko = t.keys_out, *vo = t.vals_out;
+    for (int pass = 0; pass < 2; pass++) {  // sum bits 0-7, then 8-14
+        const int shift = pass * 8;
+        hipLaunchKernelGGL(k_rs_hist, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, ki, hist, ntiles, shift);
+        hipLaunchKernelGGL(k_rs_scan, dim3(d.S), dim3(1024), 0, st, d, hist, ntiles);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, ki, vi, ko, vo, hist, ntiles, shift);
+        uint32_t *x = ki;
+        ki = ko;
+        ko = x;
+        x = vi;
+        vi = vo;
+        vo = x;
+    }
+    // after two passes the sorted pairs are back in keys_in / vals_in
+    hipLaunchKernelGGL(k_sort_finish, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, ki, vi);
+}
+
 void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStream_t st)
 {
     (void)types;
-    dim3 gi((d.W + IT_W - 1) / IT_W, (d.H + IT_H - 1) / IT_H, d.S);
-    hipLaunchKernelGGL(k_interp, gi, dim3(IT_W, IT_H), 0, st, d);
-    long long fw = (long long)(d.W >> 2) * ((d.H + FS_ROWS - 1) / FS_ROWS) * d.S;
-    hipLaunchKernelGGL(k_features, dim3((unsigned)((fw + 3) / 4)), dim3(256), 0, st, d);
-    int n = d.W * d.H;
-    hipLaunchKernelGGL(k_sort_keys, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.keys_in, t.vals_in);
-    size_t bytes = t.tmp_bytes;
-    rocprim::radix_sort_pairs(t.tmp, bytes, t.keys_in, t.keys_out, t.vals_in, t.vals_out, (size_t)n * d.S, 0,
-                              sort_end_bit(d.S), st);
-    hipLaunchKernelGGL(k_sort_finish, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.keys_out, t.vals_out);
+    fer_launch_interp(d, st);
+    fer_launch_features(d, st);
+    fer_launch_sort(d, t, st);
 }
 
 // ------------------------------------------------------------------ k_frame_sad

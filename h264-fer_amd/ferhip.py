@@ -183,15 +183,16 @@ class FerHip:
             raise FerHipError(f"ferhip_read_buffer({name}) returned {got}, expected {out.nbytes}")
         return out
 
-    PHASES = ("refprep", "me_pre", "me_resolve", "p_resid", "intra", "cavlc", "frame_sad")
+    PHASES = ("interp", "me_pre", "me_resolve", "p_resid", "intra", "cavlc", "frame_sad", "features", "sort", "me_walk")
+    NPHASE = 12
 
     def profile(self, enable=True):
         _chk(self.lib.ferhip_profile(self.ctx, int(enable)), "ferhip_profile")
 
     def get_profile(self, reset=True):
         """{phase: (milliseconds, launches)} measured with HIP events on the launch stream."""
-        ms = (C.c_double * 8)()
-        ln = (C.c_long * 8)()
+        ms = (C.c_double * self.NPHASE)()
+        ln = (C.c_long * self.NPHASE)()
         _chk(self.lib.ferhip_get_profile(self.ctx, ms, ln, int(reset)), "ferhip_get_profile")
         return {n: (ms[k], ln[k]) for k, n in enumerate(self.PHASES)}
 

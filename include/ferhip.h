@@ -99,14 +99,17 @@ const char *ferhip_version(void);
 /* Live kernel timing: when enabled every kernel group of a picture is bracketed by HIP events
  * on the launch stream.  ferhip_get_profile synchronises and returns accumulated milliseconds
  * and launch counts per phase. */
-#define FERHIP_PH_REFPREP 0    /* k_interp + k_features + sort */
-#define FERHIP_PH_ME_PRE 1     /* k_me_pre, one launch per picture */
-#define FERHIP_PH_ME_RESOLVE 2 /* k_me_resolve, one launch per MB anti-diagonal */
-#define FERHIP_PH_P_RESID 3    /* k_p_resid */
+#define FERHIP_PH_INTERP 0     /* k_interp: the 16 quarter-pel planes */
+#define FERHIP_PH_ME_PRE 1     /* k_me_pre: box sums, stage-3 search, its SADs */
+#define FERHIP_PH_ME_RESOLVE 2 /* k_me_resolve, one persistent launch per picture */
+#define FERHIP_PH_P_RESID 3    /* k_p_resid (partition merge, mvd, snapping, residual) */
 #define FERHIP_PH_INTRA 4      /* k_intra_mb, one launch per MB anti-diagonal */
 #define FERHIP_PH_CAVLC 5      /* size + scan + emit */
 #define FERHIP_PH_FRAME_SAD 6
-#define FERHIP_NPHASE 8
+#define FERHIP_PH_FEATURES 7   /* k_features: box features of every position and plane */
+#define FERHIP_PH_SORT 8       /* k_sort_keys + radix sort + k_sort_finish (bucket index) */
+#define FERHIP_PH_ME_WALK 9    /* k_me_walk: stage-2 candidate sets */
+#define FERHIP_NPHASE 12
 int ferhip_profile(ferhip_ctx *c, int enable);
 int ferhip_get_profile(ferhip_ctx *c, double *ms, long *launches, int reset);
 
@@ -114,7 +117,9 @@ int ferhip_get_profile(ferhip_ctx *c, double *ms, long *launches, int reset);
  * They operate on the pictures currently in the context, for all streams. */
 /* FillInterpolatedRefFrame(), F/moestimation.h / F/moestimation.cpp:74 */
 int ferhip_fill_interpolated(ferhip_ctx *c);
-/* motion decision of every MB = interEncoding() over the picture, F/moestimation.cpp:392 */
+/* motion decision of every MB = interEncoding() over the picture, F/moestimation.cpp:392; the partition merge
+ * shares its wavefront with the residual of the macroblock, so the picture buffers hold the reconstruction of
+ * the inter macroblocks afterwards */
 int ferhip_inter_encoding(ferhip_ctx *c);
 /* debug/test read-back of device state; which: see FERHIP_BUF_*; returns bytes copied */
 #define FERHIP_BUF_INTERP 1   /* uint8  [S][16][H][W] */
