@@ -231,10 +231,37 @@ extern "C" void ferhip_destroy(ferhip_ctx *c)
 }
 
 // [S][Y|U|V] interleaved per stream  <->  plane-major [Y of all streams][U ...][V ...]
+// I420 pictures, stream-major [S][Y|Cb|Cr] <-> the context's plane-major picture set [plane][S][...], both in
+// device memory: one launch instead of three copies per stream.  16 bytes per thread (plane sizes are multiples of 64).
+__global__ __launch_bounds__(256) void k_repack(uint8_t *set, uint8_t *frames, size_t ysz, size_t csz, int S, int to_set)
+{
+    const size_t fsz = ysz + 2 * csz;
+    const int s = blockIdx.y;
+    for (size_t o = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; o < fsz; o += (size_t)gridDim.x * blockDim.x * 16) {
+        size_t po;
+        if (o < ysz)
+            po = (size_t)s * ysz + o;
+        else if (o < ysz + csz)
+            po = (size_t)S * ysz + (size_t)s * csz + (o - ysz);
+        else
+            po = (size_t)S * (ysz + csz) + (size_t)s * csz + (o - ysz - csz);
+        uint4 *a = (uint4 *)(set + po), *b = (uint4 *)(frames + (size_t)s * fsz + o);
+        if (to_set)
+            *a = *b;
+        else
+            *b = *a;
+    }
+}
+
 static int copy_frames(ferhip_ctx *c, uint8_t *set, const uint8_t *src, uint8_t *dst, hipMemcpyKind kind)
 {
     FerDev &d = c->d;
     size_t fsz = d.ysz * 3 / 2;
+    if (kind == hipMemcpyDeviceToDevice && (((uintptr_t)(src ? src : dst)) & 15) == 0) {
+        hipLaunchKernelGGL(k_repack, dim3(256, d.S), dim3(256), 0, c->st, set, (uint8_t *)(src ? src : dst), d.ysz, d.csz, d.S,
+                           src ? 1 : 0);
+        return 0;
+    }
     for (int s = 0; s < d.S; s++) {
         uint8_t *py = set + (size_t)s * d.ysz;
         uint8_t *pu = set + (size_t)d.S * d.ysz + (size_t)s * d.csz;
