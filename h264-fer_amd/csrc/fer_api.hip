@@ -10,6 +10,8 @@
 #include <string.h>
 #include <algorithm>
 #include <utility>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #define CK(x)                                                                                         \
@@ -102,7 +104,13 @@ static void bind_planes(ferhip_ctx *c)
 
 extern "C" const char *ferhip_version(void) { return "ferhip 0.1 (gfx950)"; }
 
+static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params *p, bool decode_only);
 extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params *p)
+{
+    return ctx_create(out, W, H, S, p, false);
+}
+// decode_only: the encoder-side structures (interpolated planes, features, sort, search lists, RBSP) stay empty
+static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params *p, bool decode_only)
 {
     if (!out || !p || W <= 0 || H <= 0 || (W & 15) || (H & 15) || S <= 0 || W > 16384 || H > 16384) return FERHIP_E_ARG;
     if (p->qp < 0 || p->qp > 51 || p->window < 16 || p->intra_every <= 0) return FERHIP_E_ARG;
@@ -145,16 +153,16 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     int rc = 0;
     rc |= dalloc(c, &c->planes[0], fsz * S);
     rc |= dalloc(c, &c->planes[1], fsz * S);
-    rc |= dalloc(c, &d.interp, d.ysz * 16 * S);
-    rc |= dalloc(c, &d.feat, d.ysz * 96 * S);
-    rc |= dalloc(c, &d.feat0, d.ysz * 6 * S);
-    rc |= dalloc(c, &d.sort_pos, d.ysz * S);
-    rc |= dalloc(c, &d.sort_rec, d.ysz * S * 3);
+    rc |= dalloc(c, &d.interp, decode_only ? (size_t)1 : (size_t)(d.ysz * 16 * S));
+    rc |= dalloc(c, &d.feat, decode_only ? (size_t)1 : (size_t)(d.ysz * 96 * S));
+    rc |= dalloc(c, &d.feat0, decode_only ? (size_t)1 : (size_t)(d.ysz * 6 * S));
+    rc |= dalloc(c, &d.sort_pos, decode_only ? (size_t)1 : (size_t)(d.ysz * S));
+    rc |= dalloc(c, &d.sort_rec, decode_only ? (size_t)1 : (size_t)(d.ysz * S * 3));
     d.ktw_shift = 3;  // column tiles of the bucket index: at most 64 per row, at least 8 columns wide
     while (((W + (1 << d.ktw_shift) - 1) >> d.ktw_shift) > 64) d.ktw_shift++;
     d.kt = (W + (1 << d.ktw_shift) - 1) >> d.ktw_shift;
     const size_t nbins = (size_t)S * 16384 * d.kt + 1;
-    rc |= dalloc(c, &d.kol2, nbins);
+    rc |= dalloc(c, &d.kol2, decode_only ? (size_t)1 : (size_t)(nbins));
     size_t nm = (size_t)d.nmb * S;
     rc |= dalloc(c, &d.mb_type, nm);
     rc |= dalloc(c, &d.mv, nm * 8);
@@ -165,17 +173,17 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     rc |= dalloc(c, &d.i4flag, nm * 16);
     rc |= dalloc(c, &d.chroma_mode, nm);
     rc |= dalloc(c, &d.levels, nm * FER_LEVELS);
-    rc |= dalloc(c, &d.suma, nm * 20);
-    rc |= dalloc(c, &d.st3, nm * 4 * 33 * 3);
-    rc |= dalloc(c, &d.st3n, nm * 4);
-    rc |= dalloc(c, &d.st2, nm * 4 * FER_ST2_CAP * 2);
-    rc |= dalloc(c, &d.st2n, nm * 4);
+    rc |= dalloc(c, &d.suma, decode_only ? (size_t)1 : (size_t)(nm * 20));
+    rc |= dalloc(c, &d.st3, decode_only ? (size_t)1 : (size_t)(nm * 4 * 33 * 3));
+    rc |= dalloc(c, &d.st3n, decode_only ? (size_t)1 : (size_t)(nm * 4));
+    rc |= dalloc(c, &d.st2, decode_only ? (size_t)1 : (size_t)(nm * 4 * FER_ST2_CAP * 2));
+    rc |= dalloc(c, &d.st2n, decode_only ? (size_t)1 : (size_t)(nm * 4));
     rc |= dalloc(c, &d.chain, (size_t)64);
     rc |= dalloc(c, &d.timing, (size_t)64);
-    rc |= dalloc(c, &d.chain64, nm * 4);
+    rc |= dalloc(c, &d.chain64, decode_only ? (size_t)1 : (size_t)(nm * 4));
     rc |= dalloc(c, &d.mb_bits, ((size_t)d.nmb + 1) * S);
     d.bits_cap_words = ((size_t)d.nmb * 1024 + 4096) / 4;
-    rc |= dalloc(c, &d.bits, d.bits_cap_words * S);
+    rc |= dalloc(c, &d.bits, decode_only ? (size_t)1 : (size_t)(d.bits_cap_words * S));
     rc |= dalloc(c, &d.hdr, (size_t)4 * S);
     rc |= dalloc(c, &d.out_bytes, (size_t)S);
     rc |= dalloc(c, &d.status, (size_t)S);
@@ -184,14 +192,19 @@ extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip
     rc |= dalloc(c, &d.dec_qp, nm);
     rc |= dalloc(c, &d.dec_state, (size_t)4 * S);
     rc |= dalloc(c, &d.dec_cac, (size_t)128 * S);
+    rc |= dalloc(c, &d.dec_carry, nm);
+    rc |= dalloc(c, &d.dec_summ, (size_t)4 * S);
+    rc |= dalloc(c, &d.dec_pic_state, (size_t)4 * S);
+    rc |= dalloc(c, &d.dec_cac_in, (size_t)128 * S);
+    rc |= dalloc(c, &d.dec_cac_out, (size_t)128 * S);
     int n = W * H;
     c->sort.tmp_bytes = fer_sort_tmp_bytes(n, S);
-    rc |= dalloc(c, &c->sort.keys_in, (size_t)n * S);
-    rc |= dalloc(c, &c->sort.keys_out, (size_t)n * S);
-    rc |= dalloc(c, &c->sort.vals_in, (size_t)n * S);
-    rc |= dalloc(c, &c->sort.vals_out, (size_t)n * S);
+    rc |= dalloc(c, &c->sort.keys_in, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
+    rc |= dalloc(c, &c->sort.keys_out, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
+    rc |= dalloc(c, &c->sort.vals_in, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
+    rc |= dalloc(c, &c->sort.vals_out, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
     uint8_t *tmp = nullptr;
-    rc |= dalloc(c, &tmp, c->sort.tmp_bytes);
+    rc |= dalloc(c, &tmp, decode_only ? (size_t)1 : (size_t)(c->sort.tmp_bytes));
     c->sort.tmp = tmp;
     if (rc) {
         ferhip_destroy(c);
@@ -972,6 +985,31 @@ struct DecParams {
 };
 static DecParams *dec_params_of(ferhip_ctx *c);
 
+// the one-picture window made of the context's own side-information arrays
+static DecBatch dec_batch_of_ctx(const FerDev &d, const uint8_t *d_rbsp, const uint32_t *d_info)
+{
+    DecBatch B;
+    B.TW = 1;
+    B.mb_type = d.mb_type;
+    B.mv = d.mv;
+    B.cbp = d.cbp;
+    B.tc = d.tc;
+    B.i4mode = d.i4mode;
+    B.i4flag = d.i4flag;
+    B.chroma_mode = d.chroma_mode;
+    B.levels = d.levels;
+    B.dec_qp = d.dec_qp;
+    B.carry = d.dec_carry;
+    B.hdr = d.hdr;
+    B.state = d.dec_pic_state;
+    B.summ = d.dec_summ;
+    B.cac_in = d.dec_cac_in;
+    B.cac_out = d.dec_cac_out;
+    B.rbsp = d_rbsp;
+    B.info = d_info;
+    return B;
+}
+
 extern "C" int ferhip_decode_picture(ferhip_ctx *c, const uint8_t *rbsp, size_t stride, const uint32_t *len,
                                      const int *nal_type, const int *nal_ref_idc)
 {
@@ -984,8 +1022,10 @@ extern "C" int ferhip_decode_picture(ferhip_ctx *c, const uint8_t *rbsp, size_t 
     if (stride > dp->d_rbsp_cap / S) return FERHIP_E_ARG;
     bool anyP = false, anyI = false;
     for (int s = 0; s < S; s++) {
-        uint32_t *info = &dp->info[s * 4];
+        uint32_t *info = &dp->info[s * 6];
         info[0] = info[1] = info[2] = info[3] = 0;
+        info[4] = (uint32_t)((size_t)s * stride);
+        info[5] = (uint32_t)(((size_t)s * stride) >> 32);
         c->h_hdr[s * 4 + 3] = 2;
         if (len[s] == 0) continue;
         int ov = 0;
@@ -1001,9 +1041,14 @@ extern "C" int ferhip_decode_picture(ferhip_ctx *c, const uint8_t *rbsp, size_t 
     // `frame` keeps the previous picture where the parser does not reach (F/rbsp_decoding.cpp:77)
     CK(hipMemcpyAsync(c->planes[c->cur_set], c->planes[c->cur_set ^ 1], d.ysz * 3 / 2 * S, hipMemcpyDeviceToDevice, c->st));
     CK(hipMemcpyAsync(dp->d_rbsp, rbsp, stride * S, hipMemcpyHostToDevice, c->st));
-    CK(hipMemcpyAsync(dp->d_info, dp->info.data(), sizeof(uint32_t) * 4 * S, hipMemcpyHostToDevice, c->st));
+    CK(hipMemcpyAsync(dp->d_info, dp->info.data(), sizeof(uint32_t) * 6 * S, hipMemcpyHostToDevice, c->st));
     CK(hipMemcpyAsync(d.hdr, c->h_hdr, sizeof(uint32_t) * 4 * S, hipMemcpyHostToDevice, c->st));
-    fer_launch_decode(d, dp->d_rbsp, stride, dp->d_info, anyP, anyI, c->st);
+    fer_launch_decode_parse(d, dec_batch_of_ctx(d, dp->d_rbsp, dp->d_info), c->st);
+    {
+        FerDev ds = d;  // the reconstruction reads the per-picture state (macroblocks reached), not the carried one
+        ds.dec_state = d.dec_pic_state;
+        fer_launch_decode_recon(ds, anyP, anyI, c->st);
+    }
     CK(hipGetLastError());
     CK(hipMemcpyAsync(c->h_status, d.status, sizeof(int) * S, hipMemcpyDeviceToHost, c->st));
     CK(hipStreamSynchronize(c->st));
@@ -1031,37 +1076,50 @@ struct NalRef {
     int type, ref_idc;
     std::vector<uint8_t> rbsp;
 };
+// next position i in [from, n - 2) with s[i] == 0, s[i+1] == 0 and s[i+2] in `third` (two allowed values), or npos;
+// zero bytes are rare in entropy-coded data, so the scan is driven by memchr
+static size_t find_zz(const uint8_t *s, size_t from, size_t n, uint8_t t0, uint8_t t1)
+{
+    while (from + 2 < n) {
+        const uint8_t *p = (const uint8_t *)memchr(s + from, 0, n - 2 - from);
+        if (!p) break;
+        size_t i = (size_t)(p - s);
+        if (s[i + 1] == 0 && (s[i + 2] == t0 || s[i + 2] == t1)) return i;
+        from = i + 1;
+    }
+    return (size_t)-1;
+}
 static void split_stream(const uint8_t *s, size_t n, std::vector<NalRef> &out)
 {
     size_t pos = 0;
     for (;;) {
         size_t st = (size_t)-1;
-        for (size_t i = pos; i + 3 < n; i++)
-            if (s[i] == 0 && s[i + 1] == 0 && s[i + 2] == 0 && s[i + 3] == 1) {
-                st = i + 4;
+        for (size_t i = pos; i + 3 < n;) {  // 00 00 00 01
+            size_t z = find_zz(s, i, n - 1, 0, 0);
+            if (z == (size_t)-1) break;
+            if (s[z + 3] == 1) {
+                st = z + 4;
                 break;
             }
+            i = z + 1;
+        }
         if (st == (size_t)-1) break;
-        size_t en = n;
-        for (size_t i = st; i + 2 < n; i++)
-            if (s[i] == 0 && s[i + 1] == 0 && (s[i + 2] == 0 || s[i + 2] == 1)) {
-                en = i;
-                break;
-            }
+        size_t en = find_zz(s, st, n, 0, 1);
+        if (en == (size_t)-1) en = n;
         pos = en;
         if (en <= st) continue;
         NalRef nal;
         nal.ref_idc = (s[st] & 0x7f) >> 5;
         nal.type = s[st] & 0x1f;
-        for (size_t i = st + 1; i < en; i++) {
-            if (i + 2 < en && s[i] == 0 && s[i + 1] == 0 && s[i + 2] == 3) {
-                nal.rbsp.push_back(s[i]);
-                nal.rbsp.push_back(s[i + 1]);
-                i += 2;
-            } else {
-                nal.rbsp.push_back(s[i]);
-            }
+        nal.rbsp.reserve(en - st);
+        size_t from = st + 1;
+        for (;;) {  // drop the emulation prevention byte of every 00 00 03
+            size_t z = find_zz(s, from, en, 3, 3);
+            if (z == (size_t)-1) break;
+            nal.rbsp.insert(nal.rbsp.end(), s + from, s + z + 2);
+            from = z + 3;
         }
+        if (from < en) nal.rbsp.insert(nal.rbsp.end(), s + from, s + en);
         if (nal.rbsp.empty()) break;
         out.push_back(std::move(nal));
     }
@@ -1073,11 +1131,22 @@ extern "C" int ferhip_decode_streams(const uint8_t *const *streams, const size_t
                                      int max_pictures, int *pictures, int *W_out, int *H_out)
 {
     if (!streams || !lens || S <= 0 || !pictures) return FERHIP_E_ARG;
+    const bool verbose = getenv("FER_DEC_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_start = now(), t_parse = 0, t_recon = 0, t_pack = 0;
     std::vector<std::vector<NalRef>> nals(S);
     DecHdr h;
     memset(&h, 0, sizeof h);
+    {  // NAL splitting is host work per stream: spread it over a few threads
+        const int nth = std::max(1, std::min(std::min(S, 16), (int)std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (int k = 0; k < nth; k++)
+            th.emplace_back([&, k]() {
+                for (int s = k; s < S; s += nth) split_stream(streams[s], lens[s], nals[s]);
+            });
+        for (auto &x : th) x.join();
+    }
     for (int s = 0; s < S; s++) {
-        split_stream(streams[s], lens[s], nals[s]);
         for (auto &n : nals[s]) {
             HostBR r{n.rbsp.data(), n.rbsp.size(), 0};
             DecHdr hs = h;
@@ -1094,60 +1163,195 @@ extern "C" int ferhip_decode_streams(const uint8_t *const *streams, const size_t
     if (!h.have_sps) return FERHIP_E_ARG;
     if (W_out) *W_out = h.W;
     if (H_out) *H_out = h.H;
+    const double t_split = now();
     ferhip_ctx *c = nullptr;
     ferhip_params p = {26, 0, 16, 3, 1 << 30};
-    int rc = ferhip_create(&c, h.W, h.H, S, &p);
+    int rc = ctx_create(&c, h.W, h.H, S, &p, true);
     if (rc) return rc;
-    DecParams dp;
-    dp.h = h;
-    dp.info.assign((size_t)S * 4, 0);
-    size_t stride = 0;
-    for (int s = 0; s < S; s++)
+    FerDev &d = c->d;
+    const double t_create = now();
+    // the slice NALs of every stream, in order
+    std::vector<std::vector<const NalRef *>> slices(S);
+    size_t T = 0;
+    for (int s = 0; s < S; s++) {
         for (auto &n : nals[s])
-            if (n.type == 1 || n.type == 5) stride = std::max(stride, n.rbsp.size());
-    stride = (stride + 15) & ~(size_t)15;
-    dp.d_rbsp_cap = stride * S + 16;
-    if (hipMalloc((void **)&dp.d_rbsp, dp.d_rbsp_cap) != hipSuccess || hipMalloc((void **)&dp.d_info, sizeof(uint32_t) * 4 * S) != hipSuccess) {
-        ferhip_destroy(c);
-        return FERHIP_E_HIP;
+            if (n.type == 1 || n.type == 5) slices[s].push_back(&n);
+        T = std::max(T, slices[s].size());
+        pictures[s] = 0;
     }
-    g_dec.push_back({c, &dp});
-    std::vector<size_t> cursor(S, 0);
-    std::vector<uint8_t> rb(stride * S);
-    std::vector<uint32_t> len(S);
-    std::vector<int> nt(S), nr(S);
-    size_t fsz = (size_t)h.W * h.H * 3 / 2;
-    for (int s = 0; s < S; s++) pictures[s] = 0;
-    rc = 0;
-    for (int t = 0;; t++) {
-        bool any = false;
-        for (int s = 0; s < S; s++) {
-            len[s] = 0;
-            nt[s] = nr[s] = 0;
-            while (cursor[s] < nals[s].size() && nals[s][cursor[s]].type != 1 && nals[s][cursor[s]].type != 5) cursor[s]++;
-            if (cursor[s] < nals[s].size()) {
-                NalRef &n = nals[s][cursor[s]++];
-                memcpy(rb.data() + (size_t)s * stride, n.rbsp.data(), n.rbsp.size());
-                len[s] = (uint32_t)n.rbsp.size();
-                nt[s] = n.type;
-                nr[s] = n.ref_idc;
-                any = true;
+    if (max_pictures > 0) T = std::min(T, (size_t)max_pictures);
+    // Slice data is bit-serial, so the parser's parallelism is pictures: a window of TW pictures of all streams is
+    // parsed by one launch (one wavefront each), then reconstructed picture by picture.
+    const size_t nm = (size_t)S * d.nmb;
+    const size_t per_pic = nm * (4 + 16 + 2 + 24 + 16 + 16 + 1 + FER_LEVELS * 2 + 1 + 1);
+    size_t TWmax = std::min<size_t>(std::max<size_t>((size_t)48e9 / per_pic, 1), 256);
+    TWmax = std::max<size_t>(std::min(TWmax, T), 1);
+    std::vector<void *> wal;
+    auto wmalloc = [&](size_t bytes) -> void * {
+        void *v = nullptr;
+        if (hipMalloc(&v, bytes + 256) != hipSuccess) return nullptr;
+        wal.push_back(v);
+        return v;
+    };
+    DecBatch B;
+    B.mb_type = (int *)wmalloc(TWmax * nm * 4);
+    B.mv = (short *)wmalloc(TWmax * nm * 16);
+    B.cbp = (uint8_t *)wmalloc(TWmax * nm * 2);
+    B.tc = (uint8_t *)wmalloc(TWmax * nm * 24);
+    B.i4mode = (uint8_t *)wmalloc(TWmax * nm * 16);
+    B.i4flag = (uint8_t *)wmalloc(TWmax * nm * 16);
+    B.chroma_mode = (uint8_t *)wmalloc(TWmax * nm);
+    B.levels = (int16_t *)wmalloc(TWmax * nm * FER_LEVELS * 2);
+    B.dec_qp = (uint8_t *)wmalloc(TWmax * nm);
+    B.carry = (uint8_t *)wmalloc(TWmax * nm);
+    B.hdr = (uint32_t *)wmalloc(TWmax * S * 16);
+    B.state = (int *)wmalloc(TWmax * S * 16);
+    B.summ = (int *)wmalloc(TWmax * S * 16);
+    B.cac_in = (int16_t *)wmalloc(TWmax * S * 256);
+    B.cac_out = (int16_t *)wmalloc(TWmax * S * 256);
+    uint32_t *d_info = (uint32_t *)wmalloc(TWmax * S * 24);
+    uint8_t *d_rbsp = nullptr, *h_rbsp = nullptr;  // all slices of a window: device buffer and pinned staging
+    size_t d_rbsp_cap = 0;
+    bool alloc_ok = B.mb_type && B.mv && B.cbp && B.tc && B.i4mode && B.i4flag && B.chroma_mode && B.levels && B.dec_qp &&
+                    B.carry && B.hdr && B.state && B.summ && B.cac_in && B.cac_out && d_info;
+    const double t_alloc = now();
+    std::vector<uint32_t> info, hdr;
+    std::vector<char> anyP, anyAny;
+    const size_t fsz = (size_t)h.W * h.H * 3 / 2;
+    rc = alloc_ok ? 0 : FERHIP_E_HIP;
+    d.dec_constrained_intra = h.constrained_intra;
+    d.dec_chroma_qp_offset = h.chroma_qp_offset;
+    for (size_t t0 = 0; t0 < T && rc == 0; t0 += TWmax) {
+        const size_t TW = std::min(TWmax, T - t0);
+        double ta = now();
+        info.assign(TW * S * 6, 0);
+        hdr.assign(TW * S * 4, 0);
+        anyP.assign(TW, 0);
+        anyAny.assign(TW, 0);
+        // slice headers and the offsets of the slices in the window's RBSP buffer
+        size_t total = 0;
+        for (size_t t = 0; t < TW && rc == 0; t++)
+            for (int s = 0; s < S; s++) {
+                uint32_t *in = &info[(t * S + s) * 6];
+                hdr[(t * S + s) * 4 + 3] = 2;
+                if (t0 + t >= slices[s].size()) continue;
+                const NalRef &n = *slices[s][t0 + t];
+                int ov = 0;
+                rc = dec_parse_slice_header(h, n.rbsp.data(), n.rbsp.size(), n.type, n.ref_idc, in, ov);
+                if (rc) break;
+                in[4] = (uint32_t)total;
+                in[5] = (uint32_t)(total >> 32);
+                total += (n.rbsp.size() + 15) & ~(size_t)15;
+                hdr[(t * S + s) * 4 + 3] = in[2];
+                anyP[t] |= in[2] == 0;
+                anyAny[t] = 1;
+            }
+        if (rc) break;
+        if (total + 64 > d_rbsp_cap) {
+            if (d_rbsp) hipFree(d_rbsp);
+            if (h_rbsp) hipHostFree(h_rbsp);
+            d_rbsp = h_rbsp = nullptr;
+            d_rbsp_cap = total + total / 4 + 4096;
+            if (hipMalloc((void **)&d_rbsp, d_rbsp_cap) != hipSuccess || hipHostMalloc((void **)&h_rbsp, d_rbsp_cap) != hipSuccess) {
+                rc = FERHIP_E_HIP;
+                break;
             }
         }
-        if (!any || (max_pictures > 0 && t >= max_pictures)) break;
-        rc = ferhip_decode_picture(c, rb.data(), stride, len.data(), nt.data(), nr.data());
-        if (rc) break;
-        if (out) {
-            rc = ferhip_get_recon(c, out + (size_t)t * S * fsz, 1);
-            if (rc) break;
+        {  // gather the slices into the pinned staging buffer with a few threads, then one H2D copy
+            const int nth = std::max(1, std::min(std::min(S, 16), (int)std::thread::hardware_concurrency()));
+            std::vector<std::thread> th;
+            for (int k = 0; k < nth; k++)
+                th.emplace_back([&, k]() {
+                    for (int s = k; s < S; s += nth)
+                        for (size_t t = 0; t < TW; t++) {
+                            if (t0 + t >= slices[s].size()) continue;
+                            const NalRef &n = *slices[s][t0 + t];
+                            const uint32_t *in = &info[(t * S + s) * 6];
+                            memcpy(h_rbsp + (((size_t)in[5] << 32) | in[4]), n.rbsp.data(), n.rbsp.size());
+                        }
+                });
+            for (auto &x : th) x.join();
         }
-        for (int s = 0; s < S; s++)
-            if (len[s]) pictures[s]++;
+        if (hipMemcpyAsync(d_rbsp, h_rbsp, total, hipMemcpyHostToDevice, c->st) != hipSuccess ||
+            hipMemcpyAsync(d_info, info.data(), info.size() * 4, hipMemcpyHostToDevice, c->st) != hipSuccess ||
+            hipMemcpyAsync(B.hdr, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice, c->st) != hipSuccess) {
+            rc = FERHIP_E_HIP;
+            break;
+        }
+        B.TW = (int)TW;
+        B.rbsp = d_rbsp;
+        B.info = d_info;
+        t_pack += now() - ta;
+        ta = now();
+        fer_launch_decode_parse(d, B, c->st);
+        if (hipMemcpyAsync(c->h_status, d.status, sizeof(int) * S, hipMemcpyDeviceToHost, c->st) != hipSuccess ||
+            hipStreamSynchronize(c->st) != hipSuccess || hipGetLastError() != hipSuccess) {
+            rc = FERHIP_E_HIP;
+            break;
+        }
+        for (int s = 0; s < S && rc == 0; s++)
+            if (c->h_status[s]) {
+                fprintf(stderr, "ferhip: stream %d decode status 0x%x\n", s, c->h_status[s]);
+                rc = (c->h_status[s] & FER_ERR_DEC_UNSUPPORTED) ? FERHIP_E_UNSUP : FERHIP_E_DEVICE;
+            }
+        t_parse += now() - ta;
+        ta = now();
+        for (size_t t = 0; t < TW && rc == 0; t++) {
+            if (!anyAny[t]) break;
+            // `frame` keeps the previous picture where the parser does not reach (F/rbsp_decoding.cpp:77)
+            if (hipMemcpyAsync(c->planes[c->cur_set], c->planes[c->cur_set ^ 1], d.ysz * 3 / 2 * S, hipMemcpyDeviceToDevice,
+                               c->st) != hipSuccess) {
+                rc = FERHIP_E_HIP;
+                break;
+            }
+            FerDev ds = d;  // this picture's slice of the window
+            const size_t o = t * nm;
+            ds.mb_type = B.mb_type + o;
+            ds.mv = B.mv + o * 8;
+            ds.cbp = B.cbp + o * 2;
+            ds.tc = B.tc + o * 24;
+            ds.i4mode = B.i4mode + o * 16;
+            ds.i4flag = B.i4flag + o * 16;
+            ds.chroma_mode = B.chroma_mode + o;
+            ds.levels = B.levels + o * FER_LEVELS;
+            ds.dec_qp = B.dec_qp + o;
+            ds.hdr = B.hdr + t * S * 4;
+            ds.dec_state = B.state + t * S * 4;
+            fer_launch_decode_recon(ds, anyP[t] != 0, true, c->st);
+            c->cur_set ^= 1;  // the decoded picture becomes the reference (modificationProcess -> frameDeepCopy)
+            bind_planes(c);
+            if (out) {
+                rc = ferhip_get_recon(c, out + (t0 + t) * S * fsz, 1);
+                if (rc) break;
+            }
+            for (int s = 0; s < S; s++)
+                if (t0 + t < slices[s].size()) pictures[s]++;
+        }
+        if (rc == 0 && (hipStreamSynchronize(c->st) != hipSuccess || hipGetLastError() != hipSuccess)) rc = FERHIP_E_HIP;
+        t_recon += now() - ta;
     }
-    g_dec.pop_back();
-    hipFree(dp.d_rbsp);
-    hipFree(dp.d_info);
+    if (verbose)
+        fprintf(stderr, "ferhip_decode_streams: %d streams, %zu pictures, window %zu: split %.3f s, context %.3f s, buffers %.3f s, "
+                        "pack+H2D %.3f s, parse %.3f s, reconstruction %.3f s\n", S, T, TWmax, t_split - t_start, t_create - t_split,
+                t_alloc - t_create, t_pack, t_parse, t_recon);
+    for (int s = 0; s < S; s++) c->ss[s].have_dpb = 1;
+#ifdef FER_PROBE
+    {
+        long long tm[64];
+        hipDeviceSynchronize();
+        hipMemcpy(tm, c->d.timing, sizeof tm, hipMemcpyDeviceToHost);
+        double n = tm[52] > 0 ? (double)tm[52] : 1.0;
+        fprintf(stderr, "k_dec_parse stream 0: %lld MBs, us per MB: header %.2f residual %.2f tail %.2f skip/loop %.2f\n", tm[52],
+                tm[48] / n / 100, tm[49] / n / 100, tm[50] / n / 100, tm[51] / n / 100);
+    }
+#endif
+    hipStreamSynchronize(c->st);
+    const double t_free0 = now();
+    if (d_rbsp) hipFree(d_rbsp);
+    if (h_rbsp) hipHostFree(h_rbsp);
+    for (void *v : wal) hipFree(v);
     ferhip_destroy(c);
+    if (verbose) fprintf(stderr, "ferhip_decode_streams: release %.3f s, total %.3f s\n", now() - t_free0, now() - t_start);
     return rc;
 }
 

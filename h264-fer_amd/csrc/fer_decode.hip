@@ -21,25 +21,60 @@
 #include "fer_intra_dev.h"
 #include "fer_mvpred.h"
 
+// Bit reader over one slice: a 64-bit window of the stream starting at the 32-bit aligned position wbase
+// (big-endian), refilled 32 bits at a time from a word that was requested one refill earlier, so the parse
+// loop never waits for memory per syntax element.  Everything is wave-uniform (scalar registers / scalar loads).
 struct DecBits {
     const uint8_t *buf;
     unsigned size;  // bytes
     unsigned pos;   // bit position
+    unsigned long long win;  // stream bits [wbase, wbase + 64)
+    unsigned wbase;          // multiple of 32, pos - wbase < 32
+    unsigned nxt;            // the dword behind the window, requested but not yet looked at (raw, little-endian)
 };
 
-__device__ __forceinline__ unsigned db_peek(const DecBits &b, int n)  // n <= 25
+// raw little-endian dword at `byte` (clamped into the buffer): requested early, consumed by db_take
+__device__ __forceinline__ unsigned db_fetch(const DecBits &b, unsigned byte)
 {
-    unsigned byte = b.pos >> 3;
-    unsigned v = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) v = (v << 8) | (byte + i < b.size ? (unsigned)b.buf[byte + i] : 0u);
-    return (v << (b.pos & 7)) >> (32 - n);
+    unsigned a = min(byte, (b.size + 3u) & ~3u);  // the slice buffers are padded by 16 bytes
+    return *(const uint32_t *)(b.buf + a);
+}
+// ... as big-endian stream bits, zero past the end.  The value is the same in every lane: taking it into a scalar
+// register (only now, when the load has long returned) moves the whole reader to the scalar unit.
+__device__ __forceinline__ unsigned db_take(const DecBits &b, unsigned raw, unsigned byte)
+{
+    unsigned v = __builtin_bswap32((unsigned)__builtin_amdgcn_readfirstlane((int)raw));
+    if (byte + 4 > b.size) v = byte >= b.size ? 0u : (v & ~(0xffffffffu >> (8 * (b.size - byte))));
+    return v;
+}
+__device__ __forceinline__ void db_open(DecBits &b, const uint8_t *buf, unsigned size, unsigned pos)
+{
+    b.buf = buf;
+    b.size = size;
+    b.pos = pos;
+    b.wbase = pos & ~31u;
+    const unsigned by = b.wbase >> 3;
+    b.win = ((unsigned long long)db_take(b, db_fetch(b, by), by) << 32) | db_take(b, db_fetch(b, by + 4), by + 4);
+    b.nxt = db_fetch(b, by + 8);
+}
+__device__ __forceinline__ void db_skip(DecBits &b, unsigned n)  // n <= 32
+{
+    b.pos += n;
+    if (b.pos - b.wbase >= 32) {
+        b.win = (b.win << 32) | db_take(b, b.nxt, (b.wbase >> 3) + 8);
+        b.wbase += 32;
+        b.nxt = db_fetch(b, (b.wbase >> 3) + 8);
+    }
+}
+__device__ __forceinline__ unsigned db_peek(const DecBits &b, int n)  // 1 <= n <= 32
+{
+    return (unsigned)((b.win << (b.pos - b.wbase)) >> (64 - n));
 }
 __device__ __forceinline__ unsigned db_bits(DecBits &b, int n)
 {
     if (n == 0) return 0;
     unsigned v = db_peek(b, n);
-    b.pos += n;
+    db_skip(b, (unsigned)n);
     return v;
 }
 __device__ __forceinline__ unsigned db_bit(DecBits &b) { return db_bits(b, 1); }
@@ -47,7 +82,7 @@ __device__ __forceinline__ unsigned db_ue(DecBits &b)  // F/expgolomb.cpp:122-14
 {
     unsigned w = db_peek(b, 24);
     int z = w ? __clz((int)w) - 8 : 24;
-    b.pos += z + 1;
+    db_skip(b, (unsigned)(z + 1));
     unsigned s = db_bits(b, z);
     return (1u << z) - 1u + s;
 }
@@ -58,11 +93,111 @@ __device__ __forceinline__ int db_se(DecBits &b)
 }
 __device__ __forceinline__ bool db_more(const DecBits &b) { return (b.pos >> 3) + 1 < b.size; }
 
-// residual_block_cavlc, F/residual.cpp:1069-1386.  coef: int16 destination (maxNumCoeff entries,
-// already zero).  Returns TotalCoeff, or -1 on a malformed block.
-__device__ int dec_block(DecBits &b, int16_t *coef, int maxNumCoeff, int nC)
+// ---- decode tables: the code tables of F/residual_tables.cpp inverted once per process into direct
+// look-ups by the next bits of the stream (coeff_token: 16 bits, total_zeros: 9, run_before: 3).
+// entry = len << 8 | value, 0 = no code matches; coeff_token value = TotalCoeff << 2 | TrailingOnes.
+#define DEC_CT_SUBS 48
+struct DecLuts {
+    uint16_t ct[4][65536];   // class 0..2 by nC, 3 = chroma DC: the full 16-bit look-up (build step only)
+    // what the parse kernel keeps in LDS: coeff_token in two levels of 8 bits
+    uint16_t ct1[4][256];    // len <= 8: the entry; longer codes: 0x8000 | sub-table
+    uint16_t ct2[DEC_CT_SUBS][256];
+    uint16_t tz[15][512];    // by TotalCoeff - 1
+    uint16_t tzdc[3][8];
+    uint16_t rb[6][8];       // by zerosLeft - 1 (zerosLeft <= 6)
+    int nsub;
+};
+struct DecLutsLds {  // the same tables, resident in LDS for one parse wavefront
+    uint16_t ct1[4][256];
+    uint16_t ct2[DEC_CT_SUBS][256];
+    uint16_t tz[15][512];
+    uint16_t tzdc[3][8];
+    uint16_t rb[6][8];
+};
+static DecLuts *g_dec_luts = nullptr;
+
+// second build step: split the 16-bit coeff_token table by its first 8 bits
+__global__ void k_dec_split_luts(DecLuts *L)
 {
-    int TotalCoeff = -1, TrailingOnes = 0;
+    const int cls = blockIdx.x, p = threadIdx.x;  // 4 x 256
+    const uint16_t e0 = L->ct[cls][p << 8];
+    bool uniform = true;  // a code of <= 8 bits fills all 256 completions of its prefix
+    for (int x = 1; x < 256; x++) uniform &= L->ct[cls][(p << 8) | x] == e0;
+    if (uniform && (e0 == 0 || (e0 >> 8) <= 8)) {
+        L->ct1[cls][p] = e0;
+        return;
+    }
+    int id = atomicAdd(&L->nsub, 1);
+    if (id >= DEC_CT_SUBS) {
+        L->ct1[cls][p] = 0;
+        return;
+    }
+    L->ct1[cls][p] = (uint16_t)(0x8000 | id);
+    for (int x = 0; x < 256; x++) L->ct2[id][x] = L->ct[cls][(p << 8) | x];
+}
+
+__global__ void k_dec_build_luts(DecLuts *L)
+{
+    const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;  // 16-bit window
+    if (v < 65536) {
+        for (int cls = 0; cls < 4; cls++) {
+            uint16_t e = 0;
+            const int maxtc = cls == 3 ? 4 : 16;
+            for (int T = 0; T <= maxtc && !e; T++)
+                for (int o = 0; o <= 3 && o <= T; o++) {
+                    int len = cls == 3 ? c_ctdc_len[o][T] : c_ct_len[cls][o][T];
+                    unsigned code = cls == 3 ? c_ctdc_code[o][T] : c_ct_code[cls][o][T];
+                    if (len > 0 && (v >> (16 - len)) == code) {
+                        e = (uint16_t)((len << 8) | (T << 2) | o);
+                        break;
+                    }
+                }
+            L->ct[cls][v] = e;
+        }
+    }
+    if (v < 512)
+        for (int tcm1 = 0; tcm1 < 15; tcm1++) {
+            uint16_t e = 0;
+            for (int tz = 0; tz <= 15; tz++) {
+                int len = c_tz_len[tcm1][tz];
+                if (len > 0 && (v >> (9 - len)) == c_tz_code[tcm1][tz]) {
+                    e = (uint16_t)((len << 8) | tz);
+                    break;
+                }
+            }
+            L->tz[tcm1][v] = e;
+        }
+    if (v < 8) {
+        for (int tcm1 = 0; tcm1 < 3; tcm1++) {
+            uint16_t e = 0;
+            for (int tz = 0; tz <= 3; tz++) {
+                int len = c_tzdc_len[tcm1][tz];
+                if (len > 0 && (v >> (3 - len)) == c_tzdc_code[tcm1][tz]) {
+                    e = (uint16_t)((len << 8) | tz);
+                    break;
+                }
+            }
+            L->tzdc[tcm1][v] = e;
+        }
+        for (int zl = 0; zl < 6; zl++) {
+            uint16_t e = 0;
+            for (int k = 0; k <= zl + 1; k++) {
+                int len = c_rb_len[zl][k];
+                if (len > 0 && (v >> (3 - len)) == c_rb_code[zl][k]) {
+                    e = (uint16_t)((len << 8) | k);
+                    break;
+                }
+            }
+            L->rb[zl][v] = e;
+        }
+    }
+}
+
+// residual_block_cavlc, F/residual.cpp:1069-1386.  coef: int16 destination (maxNumCoeff entries,
+// already zero).  lvl/rn: 16-entry scratch in LDS.  Returns TotalCoeff, or -1 on a malformed block.
+__device__ int dec_block(DecBits &b, const DecLutsLds *L, int16_t *coef, int maxNumCoeff, int nC, int16_t *lvl, uint8_t *rn)
+{
+    int TotalCoeff, TrailingOnes = 0;
     if (nC >= 8) {
         unsigned v = db_bits(b, 6);
         if (v == 3) {
@@ -72,114 +207,89 @@ __device__ int dec_block(DecBits &b, int16_t *coef, int maxNumCoeff, int nC)
             TrailingOnes = (int)(v & 3);
         }
     } else {
-        unsigned w = db_peek(b, 16);
-        int maxtc = nC == -1 ? 4 : 16;
-        for (int T = 0; T <= maxtc && TotalCoeff < 0; T++)
-            for (int o = 0; o <= 3 && o <= T; o++) {
-                int len;
-                unsigned code;
-                if (nC == -1) {
-                    len = c_ctdc_len[o][T];
-                    code = c_ctdc_code[o][T];
-                } else {
-                    int cls = nC <= 1 ? 0 : (nC <= 3 ? 1 : 2);
-                    len = c_ct_len[cls][o][T];
-                    code = c_ct_code[cls][o][T];
-                }
-                if (len > 0 && (w >> (16 - len)) == code) {
-                    TotalCoeff = T;
-                    TrailingOnes = o;
-                    b.pos += len;
-                    break;
-                }
-            }
-        if (TotalCoeff < 0) return -1;
+        const int cls = nC == -1 ? 3 : (nC <= 1 ? 0 : (nC <= 3 ? 1 : 2));
+        const unsigned w16 = db_peek(b, 16);
+        unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)L->ct1[cls][w16 >> 8]);
+        if (e & 0x8000) e = (unsigned)__builtin_amdgcn_readfirstlane((int)L->ct2[e & 0x7fff][w16 & 0xff]);
+        if (e == 0) return -1;
+        db_skip(b, e >> 8);
+        TotalCoeff = (int)((e >> 2) & 31);
+        TrailingOnes = (int)(e & 3);
     }
     if (TotalCoeff == 0) return 0;
     if (TotalCoeff > maxNumCoeff) return -1;
-    int level[16], run[16];
     int suffixLength = (TotalCoeff > 10 && TrailingOnes < 3) ? 1 : 0;
     for (int i = 0; i < TotalCoeff; i++) {
+        int lev;
         if (i < TrailingOnes) {
-            level[i] = 1 - 2 * (int)db_bit(b);
+            lev = 1 - 2 * (int)db_bit(b);
         } else {
-            int prefix = 0;
-            while (db_bit(b) == 0) {
-                prefix++;
-                if (prefix > 32) return -1;
-            }
+            const unsigned w = db_peek(b, 32);
+            if (w == 0) return -1;  // level_prefix beyond 31
+            const int prefix = __clz((int)w);
+            db_skip(b, (unsigned)(prefix + 1));
             int size = (prefix == 14 && suffixLength == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffixLength);
             unsigned suffix = (size > 0 || prefix >= 14) ? db_bits(b, size) : 0;
             int levelCode = (min(prefix, 15) << suffixLength);
             if (size > 0 || prefix >= 14) levelCode += (int)suffix;
             if (prefix >= 15 && suffixLength == 0) levelCode += 15;
             if (i == TrailingOnes && TrailingOnes < 3) levelCode += 2;
-            level[i] = (levelCode & 1) == 0 ? (levelCode + 2) >> 1 : (-levelCode - 1) >> 1;
+            lev = (levelCode & 1) == 0 ? (levelCode + 2) >> 1 : (-levelCode - 1) >> 1;
             if (suffixLength == 0) suffixLength = 1;
-            if (iabs(level[i]) > (3 << (suffixLength - 1)) && suffixLength < 6) suffixLength++;
+            if (iabs(lev) > (3 << (suffixLength - 1)) && suffixLength < 6) suffixLength++;
         }
+        lvl[i] = (int16_t)lev;
     }
     int zerosLeft = 0;
     if (TotalCoeff < maxNumCoeff) {
-        unsigned w = db_peek(b, 9);
-        int found = -1;
-        int maxtz = nC == -1 ? 3 : 15;
-        for (int tz = 0; tz <= maxtz; tz++) {
-            int len = nC == -1 ? c_tzdc_len[TotalCoeff - 1][tz] : c_tz_len[TotalCoeff - 1][tz];
-            unsigned code = nC == -1 ? c_tzdc_code[TotalCoeff - 1][tz] : c_tz_code[TotalCoeff - 1][tz];
-            if (len > 0 && (w >> (9 - len)) == code) {
-                found = tz;
-                b.pos += len;
-                break;
-            }
-        }
-        if (found < 0) return -1;
-        zerosLeft = found;
+        const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane(
+            (int)(nC == -1 ? L->tzdc[TotalCoeff - 1][db_peek(b, 3)] : L->tz[TotalCoeff - 1][db_peek(b, 9)]));
+        if (e == 0) return -1;
+        db_skip(b, e >> 8);
+        zerosLeft = (int)(e & 0xff);
     }
     for (int j = 0; j < TotalCoeff - 1; j++) {
         int rb = 0;
         if (zerosLeft > 0) {
             if (zerosLeft > 6) {
                 rb = 7 - (int)db_bits(b, 3);
-                if (rb == 7)
-                    while (db_bit(b) == 0) {
-                        rb++;
-                        if (rb > 64) return -1;
-                    }
-            } else {
-                unsigned w = db_peek(b, 3);
-                int found = -1;
-                for (int k = 0; k <= zerosLeft; k++) {
-                    int len = c_rb_len[zerosLeft - 1][k];
-                    if (len > 0 && (w >> (3 - len)) == c_rb_code[zerosLeft - 1][k]) {
-                        found = k;
-                        b.pos += len;
-                        break;
-                    }
+                if (rb == 7) {
+                    const unsigned w = db_peek(b, 32);
+                    if (w == 0) return -1;
+                    const int z = __clz((int)w);
+                    db_skip(b, (unsigned)(z + 1));
+                    rb += z;
                 }
-                if (found < 0) return -1;
-                rb = found;
+            } else {
+                const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)L->rb[zerosLeft - 1][db_peek(b, 3)]);
+                if (e == 0) return -1;
+                db_skip(b, e >> 8);
+                rb = (int)(e & 0xff);
             }
         }
-        run[j] = rb;
+        rn[j] = (uint8_t)rb;
         zerosLeft -= rb;
     }
-    run[TotalCoeff - 1] = zerosLeft;
+    rn[TotalCoeff - 1] = (uint8_t)max(zerosLeft, 0);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     int coeffNum = -1;
     for (int i = TotalCoeff - 1; i >= 0; i--) {
-        coeffNum += run[i] + 1;
-        if (coeffNum >= 0 && coeffNum < maxNumCoeff) coef[coeffNum] = (int16_t)level[i];
+        coeffNum += __builtin_amdgcn_readfirstlane((int)rn[i]) + 1;
+        if (coeffNum >= 0 && coeffNum < maxNumCoeff) coef[coeffNum] = lvl[i];
     }
     return TotalCoeff;
 }
 
-// nC from global side info + the current MB's counts kept in LDS (wave-uniform)
-__device__ int dec_nC(const FerDev &d, int s, int mb, bool luma, int blk, int plane, const uint8_t *tcur, int cbpL,
-                      int cbpC)
+// What the total-coefficient prediction needs from a decoded neighbour, kept in LDS: one entry per macroblock
+// column holds the macroblock above until the current one replaces it (so entry x - 1 is the left neighbour).
+struct DecNb {
+    uint8_t tc[24];
+    uint8_t cbpL, cbpC, skip, pad;
+};
+// nC of F/residual.cpp:424-538 (wave-uniform)
+__device__ int dec_nC(const DecNb *row, int x, int y, bool luma, int blk, int plane, const uint8_t *tcur, int cbpL, int cbpC)
 {
-    const int *mbt = d.mb_type + (size_t)s * d.nmb;
-    const uint8_t *cbp = d.cbp + (size_t)s * d.nmb * 2;
-    const uint8_t *tc = d.tc + (size_t)s * d.nmb * 24;
     bool edgeA, edgeB;
     int bA, bB;
     if (luma) {
@@ -196,33 +306,37 @@ __device__ int dec_nC(const FerDev &d, int s, int mb, bool luma, int blk, int pl
     bool availA = true, availB = true;
     int nA = 0, nB = 0;
     if (edgeA) {
-        if (mb % d.mbw == 0)
+        if (x == 0)
             availA = false;
         else {
-            int m = mb - 1;
-            bool zero = luma ? ((cbp[m * 2] & (1 << (bA / 4))) == 0) : ((cbp[m * 2 + 1] & 2) == 0);
-            if (!(mbt[m] == FER_P_SKIP || zero)) nA = luma ? tc[m * 24 + bA] : tc[m * 24 + 16 + plane * 4 + bA];
+            const DecNb &m = row[x - 1];
+            bool zero = luma ? ((m.cbpL & (1 << (bA / 4))) == 0) : ((m.cbpC & 2) == 0);
+            if (!(m.skip || zero)) nA = luma ? m.tc[bA] : m.tc[16 + plane * 4 + bA];
         }
     } else {
         bool zero = luma ? ((cbpL & (1 << (bA / 4))) == 0) : ((cbpC & 2) == 0);
         if (!zero) nA = luma ? tcur[bA] : tcur[16 + plane * 4 + bA];
     }
     if (edgeB) {
-        if (mb < d.mbw)
+        if (y == 0)
             availB = false;
         else {
-            int m = mb - d.mbw;
-            bool zero = luma ? ((cbp[m * 2] & (1 << (bB / 4))) == 0) : ((cbp[m * 2 + 1] & 2) == 0);
-            if (!(mbt[m] == FER_P_SKIP || zero)) nB = luma ? tc[m * 24 + bB] : tc[m * 24 + 16 + plane * 4 + bB];
+            const DecNb &m = row[x];
+            bool zero = luma ? ((m.cbpL & (1 << (bB / 4))) == 0) : ((m.cbpC & 2) == 0);
+            if (!(m.skip || zero)) nB = luma ? m.tc[bB] : m.tc[16 + plane * 4 + bB];
         }
     } else {
         bool zero = luma ? ((cbpL & (1 << (bB / 4))) == 0) : ((cbpC & 2) == 0);
         if (!zero) nB = luma ? tcur[bB] : tcur[16 + plane * 4 + bB];
     }
-    if (availA && availB) return (nA + nB + 1) >> 1;
-    if (availA) return nA;
-    if (availB) return nB;
-    return 0;
+    int r = 0;
+    if (availA && availB)
+        r = (nA + nB + 1) >> 1;
+    else if (availA)
+        r = nA;
+    else if (availB)
+        r = nB;
+    return __builtin_amdgcn_readfirstlane(r);
 }
 
 // P macroblock vectors: PredictMV + DeriveMVs (F/mode_pred.cpp:381-482), quadrant storage
@@ -282,50 +396,114 @@ __device__ void dec_derive_mvs(const FerDev &d, short *mvs, const int *mbt, int 
     }
 }
 
-__global__ __launch_bounds__(64) void k_dec_parse(FerDev d, const uint8_t *rbsp, size_t rbsp_stride,
-                                                  const uint32_t *info /* [S][4]: bytes, first bit, slice_type%5, SliceQPy */)
+// One wavefront per (stream, picture of the window).  What a picture inherits from its predecessor -- the
+// mb_qp_delta that persists when absent and the ChromaACLevel block that persists into macroblocks without
+// residual (reference quirks) -- changes no bit position, so every picture is parsed as if it inherited zeros;
+// it reports how many macroblocks ran on the inherited delta and flags those that show the inherited block,
+// k_dec_carry hands the true values down the pictures of a stream and k_dec_patch applies them.
+#ifndef DEC_PW
+#define DEC_PW 8
+#endif  // pictures (wavefronts) per workgroup: they share the decode tables in LDS
+#define DEC_WSYNC()                                        \
+    do {                                                   \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                   \
+    } while (0)
+__global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B, const DecLuts *__restrict__ luts)
 {
-    __shared__ uint8_t tcur[24];
-    __shared__ int16_t cac[2][4][16];  // ChromaACLevel persists across macroblocks (reference quirk)
-    const int lane = threadIdx.x;
-    const int s = blockIdx.x;
-    DecBits b;
-    b.buf = rbsp + (size_t)s * rbsp_stride;
-    b.size = info[s * 4];
-    b.pos = info[s * 4 + 1];
-    const int stype = (int)info[s * 4 + 2];
-    if (b.size == 0) {  // no picture for this stream at this step
-        if (lane == 0) d.dec_state[(size_t)s * 4 + 1] = 0;
+    __shared__ uint8_t tcur_w[DEC_PW][24];
+    __shared__ int16_t cac_w[DEC_PW][2][4][16];  // ChromaACLevel persists across macroblocks (reference quirk)
+    __shared__ int16_t lvl_w[DEC_PW][16];
+    __shared__ uint8_t rn_w[DEC_PW][16];
+    __shared__ __attribute__((aligned(16))) int16_t mblv_w[DEC_PW][FER_LEVELS];  // levels of the macroblock being parsed
+    __shared__ DecLutsLds lut;
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    DecNb *row = (DecNb *)dyn_lds + (size_t)wv * d.mbw;  // [mbw] per wavefront
+    uint8_t *tcur = tcur_w[wv];
+    int16_t(*cac)[4][16] = cac_w[wv];
+    int16_t *lvl = lvl_w[wv];
+    uint8_t *rn = rn_w[wv];
+    int16_t *mblv = mblv_w[wv];
+    {  // decode tables into LDS, once per workgroup
+        const uint32_t *src = (const uint32_t *)&luts->ct1[0][0];
+        uint32_t *dst = (uint32_t *)&lut;
+        for (int i = threadIdx.x; i < (int)(sizeof(DecLutsLds) / 4); i += 64 * DEC_PW) dst[i] = src[i];
+        __syncthreads();
+    }
+    const size_t pic = (size_t)blockIdx.x * DEC_PW + wv;  // index of this picture in the window's [TW][S] arrays
+    if (pic >= (size_t)B.TW * d.S) return;
+    const int tpic = (int)(pic / d.S), s = (int)(pic % d.S);
+    const uint32_t *info = B.info + pic * 6;
+    {  // this picture's slice of the side information
+        const size_t o = (size_t)tpic * d.S * d.nmb;
+        d.mb_type = B.mb_type + o;
+        d.mv = B.mv + o * 8;
+        d.cbp = B.cbp + o * 2;
+        d.tc = B.tc + o * 24;
+        d.i4mode = B.i4mode + o * 16;
+        d.i4flag = B.i4flag + o * 16;
+        d.chroma_mode = B.chroma_mode + o;
+        d.levels = B.levels + o * FER_LEVELS;
+        d.dec_qp = B.dec_qp + o;
+    }
+    uint8_t *carry = B.carry + pic * d.nmb;
+    int *st = B.state + pic * 4, *summ = B.summ + pic * 4;
+    const int stype = (int)info[2];
+    if (info[0] == 0) {  // no picture for this stream at this step
+        if (lane == 0) {
+            st[1] = 0;
+            summ[0] = summ[3] = 0;
+        }
         return;
     }
-    int QPy = (int)info[s * 4 + 3];
+    DecBits b;
+    db_open(b, B.rbsp + (((size_t)info[5] << 32) | info[4]), info[0], info[1]);
+    int QPy = (int)info[3];
     int *mbt = d.mb_type + (size_t)s * d.nmb;
     short *mvs = d.mv + (size_t)s * d.nmb * 8;
-    int *st = d.dec_state + (size_t)s * 4;  // [0] = mb_qp_delta carried across slices
-    int mb_qp_delta = st[0];
-    for (int i = lane; i < 2 * 4 * 16; i += 64) (&cac[0][0][0])[i] = d.dec_cac[(size_t)s * 128 + i];
-    __syncthreads();
+    int mb_qp_delta = 0;  // the inherited value is added by k_dec_patch
+    bool delta_known = false, cac_known = false;
+    int n_inherit = 0;    // macroblocks whose QP step used the inherited delta
+    for (int i = lane; i < 2 * 4 * 16; i += 64) (&cac[0][0][0])[i] = 0;
+    DEC_WSYNC();
     int cur = 0;
     bool more = true;
     int mvd[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#ifdef FER_PROBE
+    long long tacc[4] = {0, 0, 0, 0}, tmark = wall_clock64();
+#define DP_MARK(k)                        \
+    {                                     \
+        long long now_ = wall_clock64();  \
+        tacc[k] += now_ - tmark;          \
+        tmark = now_;                     \
+    }
+#else
+#define DP_MARK(k)
+#endif
     while (more && cur < d.nmb) {
+        DP_MARK(3)
         if (stype != 2) {
             int run = (int)db_ue(b);
             for (int i = 0; i < run && cur < d.nmb; i++) {
                 size_t mbi = (size_t)s * d.nmb + cur;
                 mbt[cur] = FER_P_SKIP;
+                if (lane == 0) row[cur % d.mbw].skip = 1;
                 for (int k = 0; k < 4; k++) mvd[k][0] = mvd[k][1] = 0;  // ClearMVD in PredictMV
                 dec_derive_mvs(d, mvs, mbt, cur, FER_P_SKIP, mvd);
                 QPy = (QPy + mb_qp_delta + 52) % 52;
+                n_inherit += delta_known ? 0 : 1;
                 d.dec_qp[mbi] = (uint8_t)QPy;
+                if (lane == 0) carry[cur] = 0;
                 cur++;
             }
             if (cur != 0 || run > 0) more = db_more(b);
         }
         if (!(more && cur < d.nmb)) break;
         const size_t mbi = (size_t)s * d.nmb + cur;
-        int16_t *lv = d.levels + mbi * FER_LEVELS;
-        for (int i = lane; i < FER_LEVELS; i += 64) lv[i] = 0;
+        const int mbx = cur % d.mbw, mby = cur / d.mbw;
+        int16_t *lv = mblv;
+        for (int i = lane; i < FER_LEVELS / 2; i += 64) ((uint32_t *)mblv)[i] = 0;
         int t = (int)db_ue(b);
         if (t > 31 || (stype == 2 && t > 24)) {
             atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
@@ -391,52 +569,73 @@ __global__ __launch_bounds__(64) void k_dec_parse(FerDev d, const uint8_t *rbsp,
         d.cbp[mbi * 2 + 1] = (uint8_t)cbpC;
         d.chroma_mode[mbi] = (uint8_t)chroma_mode;
         for (int i = lane; i < 24; i += 64) tcur[i] = 0;
-        __syncthreads();
+        DEC_WSYNC();
+        DP_MARK(0)
         bool bad = false;
         if (cbpL > 0 || cbpC > 0 || i16) {
             mb_qp_delta = db_se(b);
+            delta_known = true;
             if (mb_qp_delta < -26 || mb_qp_delta > 25) bad = true;
             // residual(0,15), F/residual.cpp:959-1067
             if (i16 && !bad) {
-                int n = dec_block(b, lv + FER_LV_DC16, 16, dec_nC(d, s, cur, true, 0, 0, tcur, cbpL, cbpC));
+                int n = dec_block(b, &lut, lv + FER_LV_DC16, 16, dec_nC(row, mbx, mby, true, 0, 0, tcur, cbpL, cbpC), lvl, rn);
                 bad |= n < 0;
                 if (n >= 0) tcur[0] = (uint8_t)n;
-                __syncthreads();
+                DEC_WSYNC();
             }
             for (int i8 = 0; i8 < 4 && !bad; i8++)
                 if (cbpL & (1 << i8))
                     for (int i4x = 0; i4x < 4 && !bad; i4x++) {
                         int blk = i8 * 4 + i4x;
-                        int n = dec_block(b, lv + blk * 16, i16 ? 15 : 16, dec_nC(d, s, cur, true, blk, 0, tcur, cbpL, cbpC));
+                        int n = dec_block(b, &lut, lv + blk * 16, i16 ? 15 : 16, dec_nC(row, mbx, mby, true, blk, 0, tcur, cbpL, cbpC), lvl, rn);
                         bad |= n < 0;
                         if (n >= 0) tcur[blk] = (uint8_t)n;
-                        __syncthreads();
+                        DEC_WSYNC();
                     }
             for (int pl = 0; pl < 2 && !bad; pl++)
-                if (cbpC & 3) bad |= dec_block(b, lv + FER_LV_CDC + pl * 4, 4, -1) < 0;
+                if (cbpC & 3) bad |= dec_block(b, &lut, lv + FER_LV_CDC + pl * 4, 4, -1, lvl, rn) < 0;
             for (int pl = 0; pl < 2 && !bad; pl++)
                 for (int cb = 0; cb < 4 && !bad; cb++) {
                     if (cbpC & 2) {
                         for (int i = lane; i < 16; i += 64) cac[pl][cb][i] = 0;
-                        __syncthreads();
-                        int n = dec_block(b, &cac[pl][cb][0], 15, dec_nC(d, s, cur, false, cb, pl, tcur, cbpL, cbpC));
+                        DEC_WSYNC();
+                        int n = dec_block(b, &lut, &cac[pl][cb][0], 15, dec_nC(row, mbx, mby, false, cb, pl, tcur, cbpL, cbpC), lvl, rn);
                         bad |= n < 0;
                         if (n >= 0) tcur[16 + pl * 4 + cb] = (uint8_t)n;
-                        __syncthreads();
+                        DEC_WSYNC();
                     } else {
                         for (int i = lane; i < 16; i += 64) cac[pl][cb][i] = 0;
-                        __syncthreads();
+                        DEC_WSYNC();
                     }
                 }
         }
+        DP_MARK(1)
         if (bad) {
             atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
             break;
         }
         // chroma AC of this macroblock = the persistent ChromaACLevel (stale when cbp == 0)
+        if (cbpL > 0 || cbpC > 0 || i16) cac_known = true;  // every block was parsed or cleared above
+        if (lane == 0) carry[cur] = cac_known ? 0 : 1;
         for (int i = lane; i < 120; i += 64) lv[FER_LV_CAC + i] = cac[i / 60][(i % 60) / 15][i % 15];
-        for (int i = lane; i < 24; i += 64) d.tc[mbi * 24 + i] = tcur[i];
+        DEC_WSYNC();
+        {  // the finished macroblock: levels to memory (one coalesced pass), counts into the neighbour row
+            uint32_t *g = (uint32_t *)(d.levels + mbi * FER_LEVELS);
+            for (int i = lane; i < FER_LEVELS / 2; i += 64) g[i] = ((const uint32_t *)mblv)[i];
+            DecNb &me = row[mbx];
+            if (lane < 24) {
+                d.tc[mbi * 24 + lane] = tcur[lane];
+                me.tc[lane] = tcur[lane];
+            }
+            if (lane == 0) {
+                me.cbpL = (uint8_t)cbpL;
+                me.cbpC = (uint8_t)cbpC;
+                me.skip = 0;
+            }
+        }
+        DEC_WSYNC();
         QPy = (QPy + mb_qp_delta + 52) % 52;
+        n_inherit += delta_known ? 0 : 1;
         d.dec_qp[mbi] = (uint8_t)QPy;
         if (inter) {
             dec_derive_mvs(d, mvs, mbt, cur, t, mvd);
@@ -462,12 +661,63 @@ __global__ __launch_bounds__(64) void k_dec_parse(FerDev d, const uint8_t *rbsp,
         }
         more = db_more(b);
         cur++;
+        DP_MARK(2)
     }
-    __syncthreads();
-    for (int i = lane; i < 128; i += 64) d.dec_cac[(size_t)s * 128 + i] = (&cac[0][0][0])[i];
+#ifdef FER_PROBE
+    if (s == 0 && lane == 0) {
+        for (int k = 0; k < 4; k++) d.timing[48 + k] += tacc[k];
+        d.timing[52] += cur;
+    }
+#endif
+#undef DP_MARK
+    DEC_WSYNC();
+    for (int i = lane; i < 128; i += 64) B.cac_out[pic * 128 + i] = (&cac[0][0][0])[i];
     if (lane == 0) {
-        st[0] = mb_qp_delta;
         st[1] = cur;  // macroblocks reached (the rest of the picture keeps the previous content)
+        summ[0] = delta_known;
+        summ[1] = mb_qp_delta;
+        summ[2] = n_inherit;
+        summ[3] = cac_known;
+    }
+}
+
+// per stream, down the pictures of the window: what each picture inherits (FerDev.dec_state / dec_cac hold the
+// state between windows)
+__global__ __launch_bounds__(128) void k_dec_carry(FerDev d, DecBatch B)
+{
+    const int s = blockIdx.x, i = threadIdx.x;  // thread i carries ChromaACLevel entry i
+    int delta = d.dec_state[(size_t)s * 4];
+    int16_t v = d.dec_cac[(size_t)s * 128 + i];
+    for (int t = 0; t < B.TW; t++) {
+        const size_t pic = (size_t)t * d.S + s;
+        if (B.info[pic * 6] == 0) continue;
+        B.cac_in[pic * 128 + i] = v;
+        if (i == 0) B.state[pic * 4] = delta;
+        if (B.summ[pic * 4 + 0]) delta = B.summ[pic * 4 + 1];
+        if (B.summ[pic * 4 + 3]) v = B.cac_out[pic * 128 + i];
+    }
+    d.dec_cac[(size_t)s * 128 + i] = v;
+    if (i == 0) d.dec_state[(size_t)s * 4] = delta;
+}
+
+// QP of the macroblocks that ran on the inherited mb_qp_delta, chroma AC of those that show the inherited block
+__global__ __launch_bounds__(256) void k_dec_patch(FerDev d, DecBatch B)
+{
+    const int s = blockIdx.y, t = blockIdx.z;
+    const int mb = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t pic = (size_t)t * d.S + s;
+    if (mb >= B.state[pic * 4 + 1]) return;
+    const size_t mbi = pic * d.nmb + mb;
+    const int delta = B.state[pic * 4];
+    if (delta != 0) {
+        int steps = min(mb + 1, B.summ[pic * 4 + 2]);
+        int q = ((int)B.dec_qp[mbi] + steps * delta) % 52;
+        B.dec_qp[mbi] = (uint8_t)(q < 0 ? q + 52 : q);
+    }
+    if (B.carry[mbi]) {
+        int16_t *lv = B.levels + mbi * FER_LEVELS + FER_LV_CAC;
+        const int16_t *c = B.cac_in + pic * 128;
+        for (int i = 0; i < 120; i++) lv[i] = c[(i / 60) * 64 + ((i % 60) / 15) * 16 + i % 15];
     }
 }
 
@@ -652,10 +902,23 @@ __global__ __launch_bounds__(64) void k_dec_intra(FerDev d, int diag)
     recon_chroma(d, lv, lane, dec_qpc(d, QPy), &L.predC[0][0][0], Cp[0], Cp[1], Wc, xp, yp);
 }
 
-void fer_launch_decode(const FerDev &d, const uint8_t *rbsp, size_t stride, const uint32_t *info, bool anyP, bool anyIntra,
-                       hipStream_t st)
+void fer_launch_decode_parse(const FerDev &d, const DecBatch &B, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_dec_parse, dim3(d.S), dim3(64), 0, st, d, rbsp, stride, info);
+    if (!g_dec_luts) {  // once per process: invert the code tables (the buffer lives until exit)
+        if (hipMalloc((void **)&g_dec_luts, sizeof(DecLuts)) != hipSuccess) return;
+        hipMemsetAsync(g_dec_luts, 0, sizeof(DecLuts), st);
+        hipLaunchKernelGGL(k_dec_build_luts, dim3(256), dim3(256), 0, st, g_dec_luts);
+        hipLaunchKernelGGL(k_dec_split_luts, dim3(4), dim3(256), 0, st, g_dec_luts);
+    }
+    hipLaunchKernelGGL(k_dec_parse, dim3((d.S * B.TW + DEC_PW - 1) / DEC_PW), dim3(64 * DEC_PW), (size_t)DEC_PW * d.mbw * sizeof(DecNb), st, d, B,
+                       g_dec_luts);
+    hipLaunchKernelGGL(k_dec_carry, dim3(d.S), dim3(128), 0, st, d, B);
+    hipLaunchKernelGGL(k_dec_patch, dim3((d.nmb + 255) / 256, d.S, B.TW), dim3(256), 0, st, d, B);
+}
+
+// reconstruction of one picture per stream; dslice = FerDev whose side-information pointers are the picture's slice
+void fer_launch_decode_recon(const FerDev &d, bool anyP, bool anyIntra, hipStream_t st)
+{
     if (anyP) hipLaunchKernelGGL(k_dec_inter, dim3(d.nmb, d.S), dim3(64), 0, st, d);
     if (anyIntra) {
         int ndiag = d.mbw + 2 * (d.mbh - 1);

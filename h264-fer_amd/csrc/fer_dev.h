@@ -74,9 +74,34 @@ struct FerDev {
     int *stats;          // [S][5] brojTipova
     // decoder (row a19)
     uint8_t *dec_qp;     // [S][nmb] QPy of every macroblock
-    int *dec_state;      // [S][4]: mb_qp_delta carried over, macroblocks parsed
+    int *dec_state;      // [S][4]: [0] mb_qp_delta carried from picture to picture; the reconstruction kernels are given the
+                         // per-picture state here ([1] = macroblocks the parser reached)
     int16_t *dec_cac;    // [S][2][4][16] persistent ChromaACLevel
+    uint8_t *dec_carry;  // [S][nmb], int *dec_summ [S][4], cac in/out [S][128]: the one-picture DecBatch of this context
+    int *dec_summ;
+    int *dec_pic_state;  // [S][4] per-picture state of that batch ([1] = macroblocks reached); dec_state keeps what persists
+    int16_t *dec_cac_in, *dec_cac_out;
     int dec_constrained_intra, dec_chroma_qp_offset;
+};
+
+// One window of pictures of the decode twin: slice data of TW pictures x S streams is parsed in one launch, so the
+// per-picture side information carries a leading [TW] dimension; slice t of every array is exactly what the
+// reconstruction kernels see through FerDev ([S][nmb]...).
+struct DecBatch {
+    int TW;
+    int *mb_type;
+    short *mv;
+    uint8_t *cbp, *tc, *i4mode, *i4flag, *chroma_mode;
+    int16_t *levels;
+    uint8_t *dec_qp;
+    uint8_t *carry;       // [TW][S][nmb] 1 = the macroblock's chroma AC levels are the block carried into its picture
+    uint32_t *hdr;        // [TW][S][4] like FerDev.hdr (slice type in [3])
+    int *state;           // [TW][S][4]: [0] mb_qp_delta carried into the picture, [1] macroblocks reached
+    int *summ;            // [TW][S][4]: parsed a mb_qp_delta?, its last value, macroblocks before the first one, wrote chroma AC?
+    int16_t *cac_in;      // [TW][S][128] ChromaACLevel carried into the picture
+    int16_t *cac_out;     // [TW][S][128] ... left behind by it
+    const uint8_t *rbsp;  // all slices of the window
+    const uint32_t *info; // [TW][S][6]: bytes, first bit of slice_data, slice_type % 5, SliceQPy, byte offset lo, hi
 };
 
 #define FER_ERR_ST2_OVERFLOW 1

@@ -23,5 +23,5 @@ void fer_launch_p_resid(const FerDev &d, hipStream_t st);
 void fer_launch_intra(const FerDev &d, hipStream_t st);
 void fer_launch_cavlc(const FerDev &d, hipStream_t st);
 void fer_launch_block_kat(int qP, const int32_t *in, int32_t *out, int keep_dc, int inverse, size_t n, hipStream_t st);
-void fer_launch_decode(const FerDev &d, const uint8_t *rbsp, size_t stride, const uint32_t *info, bool anyP, bool anyIntra,
-                       hipStream_t st);
+void fer_launch_decode_parse(const FerDev &d, const DecBatch &B, hipStream_t st);
+void fer_launch_decode_recon(const FerDev &dslice, bool anyP, bool anyIntra, hipStream_t st);

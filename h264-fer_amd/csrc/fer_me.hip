@@ -1010,7 +1010,7 @@ __device__ __forceinline__ void nbr_locate_xy(int mbw, int mbx, int mby, int xN,
 }
 
 template <int WIN>
-__global__ __launch_bounds__(128, 2) void k_me_resolve(FerDev d)
+__global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
 {
     __shared__ __attribute__((aligned(16))) int sel_all[2][256];
     __shared__ int xch[8];

@@ -226,8 +226,9 @@ def inverse_residual(qp, blocks, keep_dc=False):
     return out
 
 
-def decode_streams(streams, max_pictures):
-    """decode() for a list of Annex-B byte strings of equal picture size -> (recon [T][S][fsz], pictures, W, H)."""
+def decode_streams(streams, max_pictures, want_pictures=True):
+    """decode() for a list of Annex-B byte strings of equal picture size -> (recon [T][S][fsz], pictures, W, H).
+    want_pictures=False leaves the decoded pictures on the device (recon is None): what tools/bench_decode.py times."""
     lib = load_library()
     S = len(streams)
     arr = (C.c_char_p * S)(*streams)
@@ -237,9 +238,9 @@ def decode_streams(streams, max_pictures):
     from . import shard
     sps = [n for n in shard.split_nals(streams[0]) if (n[4] & 31) == 7][0]
     w, h = _sps_size(sps[5:])
-    out = np.empty((max_pictures, S, w * h * 3 // 2), np.uint8)
-    _chk(lib.ferhip_decode_streams(arr, lens, S, out.ctypes.data, max_pictures, pics, C.byref(W), C.byref(H)),
-         "ferhip_decode_streams")
+    out = np.empty((max_pictures, S, w * h * 3 // 2), np.uint8) if want_pictures else None
+    _chk(lib.ferhip_decode_streams(arr, lens, S, out.ctypes.data if want_pictures else None, max_pictures, pics,
+                                   C.byref(W), C.byref(H)), "ferhip_decode_streams")
     return out, list(pics), W.value, H.value
 
 

@@ -104,6 +104,30 @@ def test_scene_cut_forces_idr(pkg, fo):
     assert types == [7, 8, 5, 1, 5, 1]
 
 
+def test_mixed_picture_types_in_one_call(pkg, fo):
+    """Streams of one context take different picture types in the same call (a scene cut in stream 1 only,
+    different IntraEvery phase is not possible, so the IDR comes from selectNALUnitType): the P-only kernels --
+    sort, persistent row chain, residual -- must skip the IDR stream's rows and leave its state alone."""
+    W, H = 176, 144
+    s0 = [pkg.gen_frame(W, H, t, 5, 2) for t in range(5)]
+    s1 = [pkg.gen_frame(W, H, t, 9, 2) for t in range(2)]
+    cut = (255 - pkg.gen_frame(W, H, 2, 11, 2)).astype(np.uint8)
+    cut[: W * H] = np.clip(cut[: W * H].astype(int), 16, 235).astype(np.uint8)
+    s1 += [cut, pkg.gen_frame(W, H, 3, 9, 2), cut]   # IDR at t = 2, 3 and 4 (every change exceeds the threshold)
+    frames = np.stack([np.stack(s0), np.stack(s1)], axis=1)
+    g = pkg.FerHip(W, H, 2, qp=12, window=16, maxdiff=3, intra_every=30)
+    streams, rec = g.encode_streams(frames, want_recon=True)
+    assert g.status() == [0, 0]
+    kinds = []
+    for s in range(2):
+        o = fo.Oracle(W, H, qp=12, window=16, maxdiff=3, intra_every=30)
+        ref, ref_rec = o.encode_stream(frames[:, s])
+        o.close()
+        assert streams[s] == ref and np.array_equal(rec[:, s], ref_rec)
+        kinds.append([n[4] & 31 for n in pkg.split_nals(ref)][2:])
+    assert kinds[0] == [5, 1, 1, 1, 1] and kinds[1][2] == 5 and 1 in kinds[1][:2]
+
+
 def test_bad_arguments_are_rejected(pkg):
     with pytest.raises(pkg.FerHipError):
         pkg.FerHip(100, 144, 1)          # not a multiple of 16
