@@ -2,11 +2,12 @@
 // the macroblock loop of RBSP_decode (F/rbsp_decoding.cpp:77-351) on the GPU.
 //
 //   k_dec_parse   slice_data parsing is bit-serial inside a slice (one slice per picture), so one
-//                 WAVEFRONT walks one picture and many pictures (streams) are parsed side by side.
-//                 All lanes execute the same, lane-independent code, which the compiler keeps in
-//                 scalar registers; it emits, per macroblock, mb_type, QP, final motion vectors
-//                 (DeriveMVs, F/mode_pred.cpp:428), Intra4x4 modes, CBP, TotalCoeff and the
-//                 coefficient levels -- CAVLC of F/residual.cpp:959-1386.
+//                 WAVEFRONT walks one picture and the parallelism is pictures: every picture of a
+//                 window of all streams is parsed by one launch (k_dec_carry / k_dec_patch then
+//                 resolve what a picture inherits from its predecessor).  The code is
+//                 lane-independent and kept on the scalar unit; it emits, per macroblock, mb_type,
+//                 QP, final motion vectors (DeriveMVs, F/mode_pred.cpp:428), Intra4x4 modes, CBP,
+//                 TotalCoeff and the coefficient levels -- CAVLC of F/residual.cpp:959-1386.
 //   k_dec_inter   every inter / P_Skip macroblock in parallel: motion compensation
 //                 (F/mocomp.cpp), dequantisation + inverse transform, clipped reconstruction.
 //   k_dec_intra   intra macroblocks along the anti-diagonal wavefront x + 2y (they read

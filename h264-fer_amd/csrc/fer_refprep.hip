@@ -345,24 +345,51 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint3
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    {  // digit tid: turn the wavefront totals into offsets behind the tile's base
-        unsigned acc = base[tid];
+    // The tile is first put in output order inside LDS (digit runs one after the other), then written out: a
+    // thread's neighbours write neighbouring addresses of the same digit run instead of 256 scattered streams.
+    __shared__ unsigned dstart[256];
+    __shared__ uint32_t sk[RS_TILE], sv[RS_TILE];
+    unsigned tot = 0;
+    {  // digit tid: wavefront totals -> offsets inside the digit's run of this tile
 #pragma unroll
         for (int w = 0; w < RS_THREADS / 64; w++) {
             unsigned c = run[w][tid];
-            run[w][tid] = acc;
-            acc += c;
+            run[w][tid] = tot;
+            tot += c;
         }
+    }
+    {  // exclusive prefix of the tile's digit totals (256 values, one per thread)
+        unsigned inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        __shared__ unsigned wsum[RS_THREADS / 64];
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        unsigned before = 0;
+        for (int w = 0; w < wv; w++) before += wsum[w];
+        dstart[tid] = before + inc - tot;
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         if (w0 + r * 64 + lane < n) {
             const unsigned dg = (key[r] >> shift) & 0xff;
-            const unsigned pos = run[wv][dg] + rk[r];
-            keys_out[pos] = key[r];
-            vals_out[pos] = val[r];
+            const unsigned lp = dstart[dg] + run[wv][dg] + rk[r];
+            sk[lp] = key[r];
+            sv[lp] = val[r];
         }
+    }
+    __syncthreads();
+    const int cnt = min(RS_TILE, n - tile * RS_TILE);
+    for (int i = tid; i < cnt; i += RS_THREADS) {
+        const uint32_t k = sk[i];
+        const unsigned dg = (k >> shift) & 0xff;
+        const unsigned pos = base[dg] + ((unsigned)i - dstart[dg]);
+        keys_out[pos] = k;
+        vals_out[pos] = sv[i];
     }
 }
 

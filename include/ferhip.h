@@ -142,8 +142,8 @@ int ferhip_set_reference(ferhip_ctx *c, const void *src);
 
 /* ---- decode twin (row a19): decode() / RBSP_decode(), F/fer_h264.cpp:26-53, F/rbsp_decoding.cpp:17 ----
  * S Annex-B streams (4-byte start codes, as the reference reads them) of equal picture size are
- * decoded side by side: slice_data parsing runs one wavefront per picture, reconstruction one
- * wavefront per macroblock.  out (host, may be NULL): [max_pictures][S][W*H*3/2], picture t of
+ * decoded side by side: slice_data parsing runs one wavefront per picture over a window of pictures of
+ * every stream at once, reconstruction one wavefront per macroblock, picture by picture.  out (host, may be NULL): [max_pictures][S][W*H*3/2], picture t of
  * stream s at (t*S + s)*W*H*3/2; pictures[s] = number decoded.  Syntax the GPU path does not
  * implement (sub-8x8 partitions, I_PCM, several reference indices) returns FERHIP_E_UNSUP. */
 int ferhip_decode_streams(const uint8_t *const *streams, const size_t *lens, int nstreams, uint8_t *out,
