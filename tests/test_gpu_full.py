@@ -87,6 +87,13 @@ def test_ragged_sizes_and_edges(pkg, fo):
         _check_against_oracle(pkg, fo, W, H, 3, 1, qp=12, window=16, intra_every=30, noise=1)
 
 
+@pytest.mark.parametrize("window", [48, 64])
+def test_other_window_sizes(pkg, fo, window):
+    """WindowSize values other than 16 / 32 take the kernels' general (not window-specialised) code: ordered list
+    insertion instead of the rank selection, the un-tiled wide search."""
+    _check_against_oracle(pkg, fo, 352, 288, 3, 2, qp=20, window=window, intra_every=30, check_streams=(0, 1))
+
+
 def test_scene_cut_forces_idr(pkg, fo):
     """selectNALUnitType: frame SAD above 16/pixel turns a P picture into IDR (F/ref_frames.cpp:210-228)."""
     W, H = 176, 144
