@@ -87,6 +87,25 @@ def test_ragged_sizes_and_edges(pkg, fo):
         _check_against_oracle(pkg, fo, W, H, 3, 1, qp=12, window=16, intra_every=30, noise=1)
 
 
+def test_1080p_full_gop(pkg, fo):
+    """A whole GOP of the benchmark workload (30 pictures, 1080p, window 32): stream 0 bit-exact against the oracle
+    over the full P chain; stream 1 through the round trip GPU encoder -> GPU decoder == encoder reconstruction."""
+    W, H, T = 1920, 1072, 30
+    frames = np.stack([np.stack([pkg.gen_frame(W, H, t, 1234 + s, 2) for s in range(2)]) for t in range(T)])
+    g = pkg.FerHip(W, H, 2, qp=12, window=32, maxdiff=3, intra_every=30)
+    streams, rec = g.encode_streams(frames, want_recon=True)
+    assert g.status() == [0, 0]
+    g.close()
+    o = fo.Oracle(W, H, qp=12, window=32, maxdiff=3, intra_every=30)
+    ref, ref_rec = o.encode_stream(frames[:, 0])
+    o.close()
+    assert streams[0] == ref
+    assert np.array_equal(rec[:, 0], ref_rec)
+    out, pics, w, h = pkg.decode_streams([streams[1]], T)
+    assert pics == [T] and (w, h) == (W, H)
+    assert np.array_equal(out[:, 0], rec[:, 1])
+
+
 @pytest.mark.parametrize("window", [48, 64])
 def test_other_window_sizes(pkg, fo, window):
     """WindowSize values other than 16 / 32 take the kernels' general (not window-specialised) code: ordered list
