@@ -192,11 +192,6 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     rc |= dalloc(c, &d.dec_qp, nm);
     rc |= dalloc(c, &d.dec_state, (size_t)4 * S);
     rc |= dalloc(c, &d.dec_cac, (size_t)128 * S);
-    rc |= dalloc(c, &d.dec_carry, nm);
-    rc |= dalloc(c, &d.dec_summ, (size_t)4 * S);
-    rc |= dalloc(c, &d.dec_pic_state, (size_t)4 * S);
-    rc |= dalloc(c, &d.dec_cac_in, (size_t)128 * S);
-    rc |= dalloc(c, &d.dec_cac_out, (size_t)128 * S);
     int n = W * H;
     c->sort.tmp_bytes = fer_sort_tmp_bytes(n, S);
     rc |= dalloc(c, &c->sort.keys_in, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
@@ -971,104 +966,6 @@ static int dec_parse_slice_header(DecHdr &h, const uint8_t *rbsp, size_t n, int 
     info[2] = (uint32_t)st;
     info[3] = (uint32_t)qp;
     return 0;
-}
-
-// RBSP_decode for one slice NAL of every stream.  rbsp host [S][stride] (len 0 = no picture for
-// that stream), nal_type / nal_ref_idc per stream; slice headers are parsed with the parameter
-// sets given to ferhip_decode_set_params.
-struct DecParams {
-    DecHdr h;
-    std::vector<uint32_t> info;
-    uint8_t *d_rbsp;
-    size_t d_rbsp_cap;
-    uint32_t *d_info;
-};
-static DecParams *dec_params_of(ferhip_ctx *c);
-
-// the one-picture window made of the context's own side-information arrays
-static DecBatch dec_batch_of_ctx(const FerDev &d, const uint8_t *d_rbsp, const uint32_t *d_info)
-{
-    DecBatch B;
-    B.TW = 1;
-    B.mb_type = d.mb_type;
-    B.mv = d.mv;
-    B.cbp = d.cbp;
-    B.tc = d.tc;
-    B.i4mode = d.i4mode;
-    B.i4flag = d.i4flag;
-    B.chroma_mode = d.chroma_mode;
-    B.levels = d.levels;
-    B.dec_qp = d.dec_qp;
-    B.carry = d.dec_carry;
-    B.hdr = d.hdr;
-    B.state = d.dec_pic_state;
-    B.summ = d.dec_summ;
-    B.cac_in = d.dec_cac_in;
-    B.cac_out = d.dec_cac_out;
-    B.rbsp = d_rbsp;
-    B.info = d_info;
-    return B;
-}
-
-extern "C" int ferhip_decode_picture(ferhip_ctx *c, const uint8_t *rbsp, size_t stride, const uint32_t *len,
-                                     const int *nal_type, const int *nal_ref_idc)
-{
-    if (!c || !rbsp || !len || !nal_type) return FERHIP_E_ARG;
-    (void)hipSetDevice(c->device);
-    DecParams *dp = dec_params_of(c);
-    if (!dp || !dp->h.have_sps) return FERHIP_E_STATE;
-    FerDev &d = c->d;
-    const int S = d.S;
-    if (stride > dp->d_rbsp_cap / S) return FERHIP_E_ARG;
-    bool anyP = false, anyI = false;
-    for (int s = 0; s < S; s++) {
-        uint32_t *info = &dp->info[s * 6];
-        info[0] = info[1] = info[2] = info[3] = 0;
-        info[4] = (uint32_t)((size_t)s * stride);
-        info[5] = (uint32_t)(((size_t)s * stride) >> 32);
-        c->h_hdr[s * 4 + 3] = 2;
-        if (len[s] == 0) continue;
-        int ov = 0;
-        int rc = dec_parse_slice_header(dp->h, rbsp + (size_t)s * stride, len[s], nal_type[s], nal_ref_idc ? nal_ref_idc[s] : 1,
-                                        info, ov);
-        if (rc) return rc;
-        c->h_hdr[s * 4 + 3] = info[2];
-        anyP |= info[2] == 0;
-        anyI = true;  // intra macroblocks may appear in any slice type
-    }
-    d.dec_constrained_intra = dp->h.constrained_intra;
-    d.dec_chroma_qp_offset = dp->h.chroma_qp_offset;
-    // `frame` keeps the previous picture where the parser does not reach (F/rbsp_decoding.cpp:77)
-    CK(hipMemcpyAsync(c->planes[c->cur_set], c->planes[c->cur_set ^ 1], d.ysz * 3 / 2 * S, hipMemcpyDeviceToDevice, c->st));
-    CK(hipMemcpyAsync(dp->d_rbsp, rbsp, stride * S, hipMemcpyHostToDevice, c->st));
-    CK(hipMemcpyAsync(dp->d_info, dp->info.data(), sizeof(uint32_t) * 6 * S, hipMemcpyHostToDevice, c->st));
-    CK(hipMemcpyAsync(d.hdr, c->h_hdr, sizeof(uint32_t) * 4 * S, hipMemcpyHostToDevice, c->st));
-    fer_launch_decode_parse(d, dec_batch_of_ctx(d, dp->d_rbsp, dp->d_info), c->st);
-    {
-        FerDev ds = d;  // the reconstruction reads the per-picture state (macroblocks reached), not the carried one
-        ds.dec_state = d.dec_pic_state;
-        fer_launch_decode_recon(ds, anyP, anyI, c->st);
-    }
-    CK(hipGetLastError());
-    CK(hipMemcpyAsync(c->h_status, d.status, sizeof(int) * S, hipMemcpyDeviceToHost, c->st));
-    CK(hipStreamSynchronize(c->st));
-    for (int s = 0; s < S; s++)
-        if (c->h_status[s]) {
-            fprintf(stderr, "ferhip: stream %d decode status 0x%x\n", s, c->h_status[s]);
-            return (c->h_status[s] & FER_ERR_DEC_UNSUPPORTED) ? FERHIP_E_UNSUP : FERHIP_E_DEVICE;
-        }
-    c->cur_set ^= 1;  // the decoded picture becomes the reference (modificationProcess -> frameDeepCopy)
-    bind_planes(c);
-    for (int s = 0; s < S; s++) c->ss[s].have_dpb = 1;
-    return 0;
-}
-
-static std::vector<std::pair<ferhip_ctx *, DecParams *>> g_dec;
-static DecParams *dec_params_of(ferhip_ctx *c)
-{
-    for (auto &p : g_dec)
-        if (p.first == c) return p.second;
-    return nullptr;
 }
 
 // split an Annex-B stream like findNALstart/findNALend/parseNAL (4-byte start codes only)

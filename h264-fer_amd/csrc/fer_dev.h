@@ -77,10 +77,6 @@ struct FerDev {
     int *dec_state;      // [S][4]: [0] mb_qp_delta carried from picture to picture; the reconstruction kernels are given the
                          // per-picture state here ([1] = macroblocks the parser reached)
     int16_t *dec_cac;    // [S][2][4][16] persistent ChromaACLevel
-    uint8_t *dec_carry;  // [S][nmb], int *dec_summ [S][4], cac in/out [S][128]: the one-picture DecBatch of this context
-    int *dec_summ;
-    int *dec_pic_state;  // [S][4] per-picture state of that batch ([1] = macroblocks reached); dec_state keeps what persists
-    int16_t *dec_cac_in, *dec_cac_out;
     int dec_constrained_intra, dec_chroma_qp_offset;
 };
 

@@ -148,10 +148,6 @@ int ferhip_set_reference(ferhip_ctx *c, const void *src);
  * implement (sub-8x8 partitions, I_PCM, several reference indices) returns FERHIP_E_UNSUP. */
 int ferhip_decode_streams(const uint8_t *const *streams, const size_t *lens, int nstreams, uint8_t *out,
                           int max_pictures, int *pictures, int *width, int *height);
-/* one slice NAL per stream on an existing context (used by ferhip_decode_streams) */
-int ferhip_decode_picture(ferhip_ctx *c, const uint8_t *rbsp, size_t stride, const uint32_t *len, const int *nal_type,
-                          const int *nal_ref_idc);
-
 /* ---- block-level KAT surface: the reference's own signatures as batched device calls ----
  * forwardResidual(qP, c, r, Intra, Intra16x16OrChroma), F/quantizationTransform.h:
  * n blocks of 16 int32 (raster) in, 16 int32 out. */
