@@ -217,6 +217,9 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     memset(c->prof_ms, 0, sizeof c->prof_ms);
     memset(c->prof_launches, 0, sizeof c->prof_launches);
     bind_planes(c);
+    // the buffers were cleared on the null stream, which the context's non-blocking streams do not wait for: without
+    // this the clearing of a large buffer can land after the first picture's kernels have written into it
+    CK(hipDeviceSynchronize());
     *out = c;
     return 0;
 }
