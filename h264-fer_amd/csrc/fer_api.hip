@@ -229,6 +229,7 @@ extern "C" void ferhip_destroy(ferhip_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     hipStreamSynchronize(c->st);
+    hipStreamSynchronize(c->st_hi);
     for (void *p : c->allocs) hipFree(p);
     if (c->h_hdr) hipHostFree(c->h_hdr);
     if (c->h_len) hipHostFree(c->h_len);
@@ -693,10 +694,19 @@ extern "C" int ferhip_encode_streams(ferhip_ctx *c, const uint8_t *frames, int n
     return 0;
 }
 
+// The context's streams are non-blocking: a synchronous copy on the null stream does not wait for them.
+static hipError_t ctx_sync(ferhip_ctx *c)
+{
+    hipError_t e = hipStreamSynchronize(c->st);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(c->st_hi);
+}
+
 extern "C" int ferhip_get_stats(ferhip_ctx *c, int *out)
 {
     if (!c || !out) return FERHIP_E_ARG;
     (void)hipSetDevice(c->device);
+    CK(ctx_sync(c));
     CK(hipMemcpy(out, c->d.stats, sizeof(int) * 5 * c->d.S, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -705,6 +715,7 @@ extern "C" int ferhip_status(ferhip_ctx *c, int *out)
 {
     if (!c || !out) return FERHIP_E_ARG;
     (void)hipSetDevice(c->device);
+    CK(ctx_sync(c));
     CK(hipMemcpy(out, c->d.status, sizeof(int) * c->d.S, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -796,6 +807,7 @@ extern "C" size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t
 {
     if (!c || !dst) return 0;
     (void)hipSetDevice(c->device);
+    if (ctx_sync(c) != hipSuccess) return 0;
     FerDev &d = c->d;
     size_t nm = (size_t)d.nmb * d.S;
     const void *src = nullptr;
