@@ -89,7 +89,8 @@ def test_ragged_sizes_and_edges(pkg, fo):
 
 def test_1080p_full_gop(pkg, fo):
     """A whole GOP of the benchmark workload (30 pictures, 1080p, window 32): stream 0 bit-exact against the oracle
-    over the full P chain; stream 1 through the round trip GPU encoder -> GPU decoder == encoder reconstruction."""
+    over the full P chain; stream 1 decoded by the GPU decoder == decoded by the oracle decoder (the reference decoder's
+    quirks can make a decoded picture differ from the encoder's reconstruction, so that is not the yardstick)."""
     W, H, T = 1920, 1072, 30
     frames = np.stack([np.stack([pkg.gen_frame(W, H, t, 1234 + s, 2) for s in range(2)]) for t in range(T)])
     g = pkg.FerHip(W, H, 2, qp=12, window=32, maxdiff=3, intra_every=30)
@@ -103,7 +104,13 @@ def test_1080p_full_gop(pkg, fo):
     assert np.array_equal(rec[:, 0], ref_rec)
     out, pics, w, h = pkg.decode_streams([streams[1]], T)
     assert pics == [T] and (w, h) == (W, H)
-    assert np.array_equal(out[:, 0], rec[:, 1])
+    n, dec, _ = fo.decode_stream_md5(streams[1])
+    assert n == T
+    for t in range(T):
+        assert np.array_equal(out[t, 0], dec[t]), f"picture {t}"
+    ys = W * H
+    for t in range(T):  # luma is not touched by those quirks
+        assert np.array_equal(out[t, 0][:ys], rec[t, 1][:ys])
 
 
 @pytest.mark.parametrize("window", [48, 64])
