@@ -1,6 +1,7 @@
 """Decode-twin throughput (row a19): S 1080p IPPP streams produced by the GPU encoder are decoded side by side by
 ferhip_decode_streams; decoded pictures stay on the device (the Annex-B input is host memory, as the reference
-reads it).  Prints macroblocks/s; checks one stream against the encoder's reconstruction first."""
+reads it).  Prints macroblocks/s; checks one stream's luma against the encoder's reconstruction first (chroma may differ
+by the reference decoder's stale-ChromaACLevel quirk; tests compare the decoder with the oracle decoder)."""
 import sys, time
 from pathlib import Path
 import numpy as np
@@ -15,7 +16,7 @@ g = pkg.FerHip(W, H, 1, qp=12, window=32, maxdiff=3, intra_every=30)
 streams, rec = g.encode_streams(base[:, None].copy(), want_recon=True)
 g.close()
 out, pics, w, h = pkg.decode_streams(streams, T)
-assert pics == [T] and np.array_equal(out[:, 0], rec[:, 0]), "decoder output differs from the encoder reconstruction"
+assert pics == [T] and np.array_equal(out[:, 0, :W * H], rec[:, 0, :W * H]), "decoded luma differs from the encoder reconstruction"
 many = [streams[0]] * S
 nmb = (W // 16) * (H // 16)
 for rep in range(2):
