@@ -549,10 +549,123 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
 
 }
 
+// ------------------------------------------------------------------ bucket walk (stage-2 candidates)
+// The bucket walk of F/moestimation.cpp:470-496.  For j = 0, 1, ... the buckets su[0]-j and su[0]+j are scanned in
+// (tx, ty) order; a candidate passes when it is inside the 280-diamond and its two half sums are within 100; the
+// walk stops after the j that takes the count past 128 (bucket su[0] is visited twice at j = 0, like the
+// reference).  Buckets are entered through the column-tile index, so only the slice whose tx can pass is read,
+// and the slices are cut into 64-entry batches that are fetched two ahead of the one being filtered (each
+// record is one 12-byte load; the exact filter decides, so the candidate set and its order are the reference's).
+// sink(ok, rank, rel, D) is called for every batch by all lanes: ok = the lane holds a candidate, rank = its
+// arrival index, rel = (tx - sx) << 16 | (ty - sy) & 0xffff, D = its feature distance.  Returns the count.
+template <class SINK>
+__device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&su)[5], const SuPk &sp, int sx, int sy, int lane,
+                                            SINK sink)
+{
+    int tren = 0;
+    if (d.basic || (d.dbg & 8)) return 0;
+    const int kt = d.kt;
+    const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * kt;
+    const uint32_t *srec = d.sort_rec;  // indexed by the device-wide positions kol2 holds
+    const int t_lo = max(sx - 279, 0) >> d.ktw_shift, t_hi = min(sx + 279, d.W - 1) >> d.ktw_shift;
+    // slice generator state (wave-uniform): bounds of 64 steps j on both sides live one per lane
+    int jn = 0, side = 0;             // next slice to open
+    unsigned cur = 0, end = 0;        // rest of the open slice
+    int cur_a = 0, cur_last = 0;      // its bucket; 1 = second side of its j (the stop test follows it)
+    unsigned kl0 = 0, kl1 = 0, kh0 = 0, kh1 = 0;
+    bool open = false, done = false;
+    // next batch: start index, entry count (0 = nothing to read), bucket, flags (1 = stop test after it, 2 = end of walk)
+    auto gen = [&](unsigned &b_start, int &b_cnt, int &b_a, int &b_flags) {
+        b_start = 0;
+        b_cnt = 0;
+        b_a = 0;
+        b_flags = 0;
+        if (done) {
+            b_flags = 2;
+            return;
+        }
+        if (!open) {
+            if (jn > 180) {
+                done = true;
+                b_flags = 2;
+                return;
+            }
+            if (side == 0 && (jn & 63) == 0) {  // bucket bounds of the next 64 steps, one step per lane
+                int al = su[0] - (jn + lane), ah = su[0] + (jn + lane);
+                bool vl = al >= 0 && al < 16384, vh = ah >= 0 && ah < 16384;
+                kl0 = vl ? kol2[(size_t)al * kt + t_lo] : 0u;
+                kl1 = vl ? kol2[(size_t)al * kt + t_hi + 1] : 0u;
+                kh0 = vh ? kol2[(size_t)ah * kt + t_lo] : 0u;
+                kh1 = vh ? kol2[(size_t)ah * kt + t_hi + 1] : 0u;
+            }
+            cur = (unsigned)lane_bcast((int)(side ? kh0 : kl0), jn & 63);
+            end = (unsigned)lane_bcast((int)(side ? kh1 : kl1), jn & 63);
+            cur_a = side ? su[0] + jn : su[0] - jn;
+            cur_last = side;
+            open = true;
+            if (side) jn++;
+            side ^= 1;
+        }
+        b_start = cur;
+        b_cnt = end > cur ? (int)min(end - cur, 64u) : 0;
+        b_a = cur_a;
+        cur += 64;
+        if (cur >= end) {
+            open = false;
+            b_flags = cur_last;
+        }
+    };
+    auto fetch = [&](unsigned b_start, int b_cnt, uint32_t &r0, uint32_t &r1, uint32_t &r2) {
+        const uint32_t *e = srec + (size_t)(b_start + (unsigned)min(lane, max(b_cnt - 1, 0))) * 3;
+        r0 = e[0];
+        r1 = e[1];
+        r2 = e[2];
+    };
+    const uint32_t sxy = ((uint32_t)sx << 16) | (uint32_t)sy;  // the records' (tx << 16) | ty pairing
+    auto filter = [&](int b_cnt, int a, uint32_t r0, uint32_t r1, uint32_t r2) {
+        // |tx - sx| + |ty - sy| < 280 and both half sums within 100, on u16 pairs
+        uint32_t dist = __builtin_amdgcn_sad_u16(r0, sxy, 0);
+        uint32_t e12 = pk_abs16(pk_sub16(r1, sp.s12));
+        bool ok = lane < b_cnt && dist < 280u && (pk_sub16(e12, 0x00640064u) & 0x80008000u) == 0x80008000u;
+        unsigned long long mk = __ballot(ok);
+        int rank = tren + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+        // feature distance from the sorted payload (kar0 == a): |s0-a| + sum |si-qi| + sum |(s0-si) - (a-qi)|
+        uint32_t aa = (uint32_t)a | ((uint32_t)a << 16);
+        uint32_t D = __builtin_amdgcn_sad_u16(r1, sp.s12, (uint32_t)iabs(su[0] - a));
+        D = __builtin_amdgcn_sad_u16(r2, sp.s34, D);
+        D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r1), sp.e12, D);
+        D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r2), sp.e34, D);
+        sink(ok, rank, (int)pk_sub16(r0, sxy), (int)D);
+        tren += __popcll(mk);
+    };
+    unsigned sA, sB;
+    int cA, cB, aA, aB, fA, fB;
+    uint32_t A0, A1, A2, B0, B1, B2;
+    gen(sA, cA, aA, fA);
+    fetch(sA, cA, A0, A1, A2);
+    gen(sB, cB, aB, fB);
+    fetch(sB, cB, B0, B1, B2);
+    for (;;) {  // two batches in flight, no register copies between them
+        if (fA & 2) break;
+        filter(cA, aA, A0, A1, A2);
+        if ((fA & 1) && tren > 128) break;
+        gen(sA, cA, aA, fA);
+        fetch(sA, cA, A0, A1, A2);
+        if (fB & 2) break;
+        filter(cB, aB, B0, B1, B2);
+        if ((fB & 1) && tren > 128) break;
+        gen(sB, cB, aB, fB);
+        fetch(sB, cB, B0, B1, B2);
+    }
+    return tren;
+}
+
 // ------------------------------------------------------------------ k_me_walk
-// Stage-2 candidate set of every 8x8 partition: the bucket walk of F/moestimation.cpp:470-496 (the
-// predictor weight is applied later, in k_me_resolve).  Kept apart from k_me_pre because it is a
-// latency-bound stream of 12-byte records that wants many resident wavefronts and few registers.
+// Stage-2 candidate set of every 8x8 partition (the predictor weight is applied later, in k_me_resolve): the first
+// FER_ST2_CAP candidates and their count.  A partition with more candidates than that -- large flat areas, where
+// thousands of positions share one feature vector -- is walked again by k_me_resolve, which then knows the predictor
+// and keeps an exact running top-33.  Kept apart from k_me_pre because it is a stream of 12-byte records that
+// wants many resident wavefronts and few registers.
 __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
 {
     const int lane = threadIdx.x;
@@ -573,116 +686,11 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
     su[3] = wave_sum((py & 3) > 1 ? 0 : v);
     su[4] = wave_sum((px & 3) > 1 ? 0 : v);
     const SuPk sp = su_pack(su);
-
-    // For j = 0, 1, ... the buckets su[0]-j and su[0]+j are scanned in (tx, ty) order; a candidate passes when it is
-    // inside the 280-diamond and its two half sums are within 100; the walk stops after the j that takes the count
-    // past 128.  Buckets are entered through the column-tile index, so only the slice whose tx can pass is read,
-    // and the slices are cut into 64-entry batches that are fetched two ahead of the one being filtered (each
-    // record is one 12-byte load; the exact filter decides, so the candidate set and its order are the reference's).
-    int tren = 0;
-    if (!d.basic && !(d.dbg & 8)) {
-        const int kt = d.kt;
-        const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * kt;
-        const uint32_t *srec = d.sort_rec;  // indexed by the device-wide positions kol2 holds
-        const int t_lo = max(sx - 279, 0) >> d.ktw_shift, t_hi = min(sx + 279, W - 1) >> d.ktw_shift;
-        const unsigned long long ltm = (1ull << lane) - 1ull;
-        // slice generator state (wave-uniform): bounds of 64 steps j on both sides live one per lane
-        int jn = 0, side = 0;             // next slice to open
-        unsigned cur = 0, end = 0;        // rest of the open slice
-        int cur_a = 0, cur_last = 0;      // its bucket; 1 = second side of its j (the stop test follows it)
-        unsigned kl0 = 0, kl1 = 0, kh0 = 0, kh1 = 0;
-        bool open = false, done = false;
-        // next batch: start index, entry count (0 = nothing to read), bucket, flags (1 = stop test after it, 2 = end of walk)
-        auto gen = [&](unsigned &b_start, int &b_cnt, int &b_a, int &b_flags) {
-            b_start = 0;
-            b_cnt = 0;
-            b_a = 0;
-            b_flags = 0;
-            if (done) {
-                b_flags = 2;
-                return;
-            }
-            if (!open) {
-                if (jn > 180) {
-                    done = true;
-                    b_flags = 2;
-                    return;
-                }
-                if (side == 0 && (jn & 63) == 0) {  // bucket bounds of the next 64 steps, one step per lane
-                    int al = su[0] - (jn + lane), ah = su[0] + (jn + lane);
-                    bool vl = al >= 0 && al < 16384, vh = ah >= 0 && ah < 16384;
-                    kl0 = vl ? kol2[(size_t)al * kt + t_lo] : 0u;
-                    kl1 = vl ? kol2[(size_t)al * kt + t_hi + 1] : 0u;
-                    kh0 = vh ? kol2[(size_t)ah * kt + t_lo] : 0u;
-                    kh1 = vh ? kol2[(size_t)ah * kt + t_hi + 1] : 0u;
-                }
-                cur = (unsigned)lane_bcast((int)(side ? kh0 : kl0), jn & 63);
-                end = (unsigned)lane_bcast((int)(side ? kh1 : kl1), jn & 63);
-                cur_a = side ? su[0] + jn : su[0] - jn;
-                cur_last = side;
-                open = true;
-                if (side) jn++;
-                side ^= 1;
-            }
-            b_start = cur;
-            b_cnt = end > cur ? (int)min(end - cur, 64u) : 0;
-            b_a = cur_a;
-            cur += 64;
-            if (cur >= end) {
-                open = false;
-                b_flags = cur_last;
-            }
-        };
-        auto fetch = [&](unsigned b_start, int b_cnt, uint32_t &r0, uint32_t &r1, uint32_t &r2) {
-            const uint32_t *e = srec + (size_t)(b_start + (unsigned)min(lane, max(b_cnt - 1, 0))) * 3;
-            r0 = e[0];
-            r1 = e[1];
-            r2 = e[2];
-        };
-        const uint32_t sxy = ((uint32_t)sx << 16) | (uint32_t)sy;  // the records' (tx << 16) | ty pairing
-        auto filter = [&](int b_cnt, int a, uint32_t r0, uint32_t r1, uint32_t r2) {
-            // |tx - sx| + |ty - sy| < 280 and both half sums within 100, on u16 pairs
-            uint32_t dist = __builtin_amdgcn_sad_u16(r0, sxy, 0);
-            uint32_t e12 = pk_abs16(pk_sub16(r1, sp.s12));
-            bool ok = lane < b_cnt && dist < 280u && (pk_sub16(e12, 0x00640064u) & 0x80008000u) == 0x80008000u;
-            unsigned long long mk = __ballot(ok);
-            int rank = tren + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-            // feature distance from the sorted payload (kar0 == a): |s0-a| + sum |si-qi| + sum |(s0-si) - (a-qi)|
-            uint32_t aa = (uint32_t)a | ((uint32_t)a << 16);
-            uint32_t D = __builtin_amdgcn_sad_u16(r1, sp.s12, (uint32_t)iabs(su[0] - a));
-            D = __builtin_amdgcn_sad_u16(r2, sp.s34, D);
-            D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r1), sp.e12, D);
-            D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r2), sp.e34, D);
-            if (ok && rank < FER_ST2_CAP) {
-                int2 *o = (int2 *)(d.st2 + (pidx * FER_ST2_CAP + rank) * 2);
-                *o = make_int2((int)pk_sub16(r0, sxy), (int)D);  // (tx - sx) << 16 | (ty - sy) & 0xffff
-            }
-            tren += __popcll(mk);
-        };
-        unsigned sA, sB;
-        int cA, cB, aA, aB, fA, fB;
-        uint32_t A0, A1, A2, B0, B1, B2;
-        gen(sA, cA, aA, fA);
-        fetch(sA, cA, A0, A1, A2);
-        gen(sB, cB, aB, fB);
-        fetch(sB, cB, B0, B1, B2);
-        for (;;) {  // two batches in flight, no register copies between them
-            if (fA & 2) break;
-            filter(cA, aA, A0, A1, A2);
-            if ((fA & 1) && tren > 128) break;
-            gen(sA, cA, aA, fA);
-            fetch(sA, cA, A0, A1, A2);
-            if (fB & 2) break;
-            filter(cB, aB, B0, B1, B2);
-            if ((fB & 1) && tren > 128) break;
-            gen(sB, cB, aB, fB);
-            fetch(sB, cB, B0, B1, B2);
-        }
-    }
-    if (lane == 0) {
-        d.st2n[pidx] = tren;
-        if (tren > FER_ST2_CAP) atomicOr(&d.status[s], FER_ERR_ST2_OVERFLOW);
-    }
+    int2 *out = (int2 *)(d.st2 + pidx * FER_ST2_CAP * 2);
+    const int tren = walk_buckets(d, s, su, sp, sx, sy, lane, [&](bool ok, int rank, int rel, int D) {
+        if (ok && rank < FER_ST2_CAP) out[rank] = make_int2(rel, D);
+    });
+    if (lane == 0) d.st2n[pidx] = tren;
 }
 
 // SAD of up to K list entries, 8 per round (lane = candidate*8 + row), and the lane's best
@@ -754,7 +762,7 @@ __device__ __forceinline__ void take_best(int best, int bestxy, int &bmin, int &
 #define RES_SPIN_LIMIT (1 << 23)
 
 struct ResPre {  // predictor-independent operands of one partition (role 1 needs all, role 0 the last two lines)
-    int n2, n3;
+    int n2, n3, n2raw;
     int2 e2[FER_ST2_CAP / 64];
     int c3x, c3y, c3s;
     int su[5];
@@ -765,12 +773,13 @@ __device__ __forceinline__ void res_prefetch(const FerDev &d, int s, int gx, int
 {
     const int mb = (gy >> 1) * d.mbw + (gx >> 1), part = (gy & 1) * 2 + (gx & 1);
     const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
-    p.n2 = p.n3 = 0;
+    p.n2 = p.n3 = p.n2raw = 0;
     p.c3x = p.c3y = p.c3s = 0;
 #pragma unroll
     for (int u = 0; u < FER_ST2_CAP / 64; u++) p.e2[u] = make_int2(0, 0);
     if (role == 1) {
-        p.n2 = min(d.st2n[pidx], FER_ST2_CAP);
+        p.n2raw = d.st2n[pidx];
+        p.n2 = min(p.n2raw, FER_ST2_CAP);
         p.n3 = (d.dbg & 64) ? 0 : d.st3n[pidx];
         const int2 *c2 = (const int2 *)(d.st2 + pidx * FER_ST2_CAP * 2);
 #pragma unroll
@@ -954,17 +963,30 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
     int mvpx, mvpy;
     predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
     const int genx = mvpx >> 2, geny = mvpy >> 2;
-    int m2[FER_ST2_CAP / 64];
-#pragma unroll
-    for (int u = 0; u < FER_ST2_CAP / 64; u++) {
-        int cc = u * 64 + lane;
-        int tx = P.e2[u].x >> 16, ty = (int)(short)(P.e2[u].x & 0xffff);  // k_me_walk stores (tx << 16) | (ty & 0xffff)
-        m2[u] = cc < P.n2 ? (iabs(tx - genx) + iabs(ty - geny) + 4) * P.e2[u].y : -1;
-    }
-    auto raw2 = [&](int u) { return P.e2[u].x; };
-    auto fin2 = [&](int e) { return pack_xy((e >> 16) * 4, (int)(short)(e & 0xffff) * 4); };
     WList L2;
-    select_topk<FER_ST2_CAP / 64>(m2, 33, lane, sel_lds, L2, raw2, fin2);
+    if (P.n2raw > FER_ST2_CAP) {
+        // more candidates than k_me_walk keeps (flat areas): walk the buckets again, now that the predictor is known,
+        // through an exact running top-33 (ordered insertion = the reference's own list update)
+        L2.m = INF_M;
+        L2.xy = 0;
+        const SuPk sp = su_pack(P.su);
+        walk_buckets(d, s, P.su, sp, sx, sy, lane, [&](bool ok, int rank, int rel, int D) {
+            (void)rank;
+            int tx = rel >> 16, ty = (int)(short)(rel & 0xffff);
+            wl_insert(L2, 33, lane, ok, (iabs(tx - genx) + iabs(ty - geny) + 4) * D, pack_xy(tx * 4, ty * 4));
+        });
+    } else {
+        int m2[FER_ST2_CAP / 64];
+#pragma unroll
+        for (int u = 0; u < FER_ST2_CAP / 64; u++) {
+            int cc = u * 64 + lane;
+            int tx = P.e2[u].x >> 16, ty = (int)(short)(P.e2[u].x & 0xffff);  // k_me_walk stores (tx << 16) | (ty & 0xffff)
+            m2[u] = cc < P.n2 ? (iabs(tx - genx) + iabs(ty - geny) + 4) * P.e2[u].y : -1;
+        }
+        auto raw2 = [&](int u) { return P.e2[u].x; };
+        auto fin2 = [&](int e) { return pack_xy((e >> 16) * 4, (int)(short)(e & 0xffff) * 4); };
+        select_topk<FER_ST2_CAP / 64>(m2, 33, lane, sel_lds, L2, raw2, fin2);
+    }
     const int cnt2 = __popcll(__ballot(lane < 33 && L2.m < 100000000));
     int b2, b2xy;
     sad_keys<33>(L2, cnt2, lane, Ps, ysz, W, H, sx, sy, P.src0, P.src1, mvpx, mvpy, b2, b2xy);

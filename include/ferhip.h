@@ -91,7 +91,7 @@ int ferhip_encode_streams(ferhip_ctx *c, const uint8_t *frames, int nframes, uin
 
 /* statistics of Starter::DohvatiStatistiku: brojTipova[5] per stream, accumulated */
 int ferhip_get_stats(ferhip_ctx *c, int *counts5_per_stream);
-/* sticky device error flags per stream (bit 0: stage-2 candidate overflow, bit 1: an 8x8
+/* sticky device error flags per stream (bit 0: unused, bit 1: an 8x8
  * block of the reference picture sums to 0, bit 2: RBSP buffer overflow) */
 int ferhip_status(ferhip_ctx *c, int *flags_per_stream);
 const char *ferhip_version(void);

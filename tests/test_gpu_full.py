@@ -120,6 +120,34 @@ def test_other_window_sizes(pkg, fo, window):
     _check_against_oracle(pkg, fo, 352, 288, 3, 2, qp=20, window=window, intra_every=30, check_streams=(0, 1))
 
 
+@pytest.mark.parametrize("kind", ["flat", "half", "bars"])
+def test_flat_areas_overflow_the_candidate_lists(pkg, fo, kind):
+    """Large flat areas: thousands of positions share one feature vector, the stage-2 candidate set of a partition
+    outgrows what k_me_walk keeps and k_me_resolve walks the buckets again with an exact running top-33."""
+    W, H, T = 352, 288, 3
+    frames = []
+    for t in range(T):
+        f = pkg.gen_frame(W, H, t, 77, 2).copy()
+        y = f[: W * H].reshape(H, W)
+        if kind == "flat":
+            y[:] = 128
+        elif kind == "half":
+            y[:, : W // 2] = 100
+        else:  # letterbox
+            y[:32] = 16
+            y[-32:] = 16
+        frames.append(f)
+    frames = np.stack(frames)[:, None]
+    g = pkg.FerHip(W, H, 1, qp=20, window=32, maxdiff=3, intra_every=30)
+    streams, rec = g.encode_streams(frames, want_recon=True)
+    assert g.status() == [0]
+    g.close()
+    o = fo.Oracle(W, H, qp=20, window=32, maxdiff=3, intra_every=30)
+    ref, ref_rec = o.encode_stream(frames[:, 0])
+    o.close()
+    assert streams[0] == ref and np.array_equal(rec[:, 0], ref_rec)
+
+
 def test_scene_cut_forces_idr(pkg, fo):
     """selectNALUnitType: frame SAD above 16/pixel turns a P picture into IDR (F/ref_frames.cpp:210-228)."""
     W, H = 176, 144
