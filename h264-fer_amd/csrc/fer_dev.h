@@ -42,6 +42,7 @@ struct FerDev {
     // t == kt is the next bucket's first.  koliko[a] of the reference = kol2[(s*16384 + a)*kt] - s*W*H.
     uint32_t *kol2;      // [S*16384*kt + 1]
     int kt, ktw_shift;
+    int *zero_cnt;       // [S] positions of the reference picture whose 8x8 sum is 0 (see "bucket 0" in k_sort_finish)
     // per-MB side information (a20)
     int *mb_type;        // [S][nmb]
     int *prev_mb_type;   // [S][nmb] mb_type_array left by the previous picture

@@ -567,7 +567,22 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
     const int kt = d.kt;
     const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * kt;
     const uint32_t *srec = d.sort_rec;  // indexed by the device-wide positions kol2 holds
-    const int t_lo = max(sx - 279, 0) >> d.ktw_shift, t_hi = min(sx + 279, d.W - 1) >> d.ktw_shift;
+    // A stream whose reference picture has n0 > 0 positions of sum 0 carries the reference's mis-filed bucket layout
+    // (k_sort_finish): whole buckets are scanned by its rules -- bucket 0 = [0, 2 n0), bucket 1 from 2 n0, the others
+    // n0 places early, the last one up to the end of the array --, and a record may sit in a bucket it does not
+    // belong to (or be left over from the previous picture), so its distance is taken from the features at its
+    // position, as the reference does, not from the record.
+    const int n0 = d.zero_cnt[s];
+    const bool quirk = n0 > 0;
+    const uint32_t npos = (uint32_t)(d.W * d.H), g0 = (uint32_t)s * npos;
+    const uint16_t *F0 = d.feat0 + (size_t)s * 6 * d.ysz;
+    const int t_lo = quirk ? 0 : (max(sx - 279, 0) >> d.ktw_shift), t_hi = quirk ? kt - 1 : (min(sx + 279, d.W - 1) >> d.ktw_shift);
+    auto qstart = [&](int a) -> uint32_t {  // first place of bucket a in the mis-filed layout
+        if (a <= 0) return g0;
+        if (a == 1) return g0 + min(2u * (uint32_t)n0, npos);
+        if (a >= 16384) return g0 + npos;
+        return kol2[(size_t)a * kt] - (uint32_t)n0;
+    };
     // slice generator state (wave-uniform): bounds of 64 steps j on both sides live one per lane
     int jn = 0, side = 0;             // next slice to open
     unsigned cur = 0, end = 0;        // rest of the open slice
@@ -593,10 +608,17 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
             if (side == 0 && (jn & 63) == 0) {  // bucket bounds of the next 64 steps, one step per lane
                 int al = su[0] - (jn + lane), ah = su[0] + (jn + lane);
                 bool vl = al >= 0 && al < 16384, vh = ah >= 0 && ah < 16384;
-                kl0 = vl ? kol2[(size_t)al * kt + t_lo] : 0u;
-                kl1 = vl ? kol2[(size_t)al * kt + t_hi + 1] : 0u;
-                kh0 = vh ? kol2[(size_t)ah * kt + t_lo] : 0u;
-                kh1 = vh ? kol2[(size_t)ah * kt + t_hi + 1] : 0u;
+                if (!quirk) {
+                    kl0 = vl ? kol2[(size_t)al * kt + t_lo] : 0u;
+                    kl1 = vl ? kol2[(size_t)al * kt + t_hi + 1] : 0u;
+                    kh0 = vh ? kol2[(size_t)ah * kt + t_lo] : 0u;
+                    kh1 = vh ? kol2[(size_t)ah * kt + t_hi + 1] : 0u;
+                } else {
+                    kl0 = vl ? qstart(al) : 0u;
+                    kl1 = vl ? qstart(al + 1) : 0u;
+                    kh0 = vh ? qstart(ah) : 0u;
+                    kh1 = vh ? qstart(ah + 1) : 0u;
+                }
             }
             cur = (unsigned)lane_bcast((int)(side ? kh0 : kl0), jn & 63);
             end = (unsigned)lane_bcast((int)(side ? kh1 : kl1), jn & 63);
@@ -629,12 +651,18 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
         bool ok = lane < b_cnt && dist < 280u && (pk_sub16(e12, 0x00640064u) & 0x80008000u) == 0x80008000u;
         unsigned long long mk = __ballot(ok);
         int rank = tren + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-        // feature distance from the sorted payload (kar0 == a): |s0-a| + sum |si-qi| + sum |(s0-si) - (a-qi)|
-        uint32_t aa = (uint32_t)a | ((uint32_t)a << 16);
-        uint32_t D = __builtin_amdgcn_sad_u16(r1, sp.s12, (uint32_t)iabs(su[0] - a));
-        D = __builtin_amdgcn_sad_u16(r2, sp.s34, D);
-        D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r1), sp.e12, D);
-        D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r2), sp.e34, D);
+        uint32_t D;
+        if (!quirk) {
+            // feature distance from the sorted payload (kar0 == a): |s0-a| + sum |si-qi| + sum |(s0-si) - (a-qi)|
+            uint32_t aa = (uint32_t)a | ((uint32_t)a << 16);
+            D = __builtin_amdgcn_sad_u16(r1, sp.s12, (uint32_t)iabs(su[0] - a));
+            D = __builtin_amdgcn_sad_u16(r2, sp.s34, D);
+            D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r1), sp.e12, D);
+            D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r2), sp.e34, D);
+        } else {
+            int px = min((int)(r0 >> 16), d.W - 1), py = min((int)(r0 & 0xffff), d.H - 1);
+            D = (uint32_t)feat_dist_rec(F0 + ((size_t)py * d.W + px) * 6, sp);
+        }
         sink(ok, rank, (int)pk_sub16(r0, sxy), (int)D);
         tren += __popcll(mk);
     };

@@ -182,12 +182,30 @@ __global__ void k_sort_keys(FerDev d, uint32_t *keys, uint32_t *vals)
     uint16_t k = d.feat0[((size_t)s * d.ysz + (size_t)ty * d.W + tx) * 6];
     keys[(size_t)s * n + b] = k;
     vals[(size_t)s * n + b] = ((uint32_t)tx << 16) | (uint32_t)ty;
-    if (k == 0) atomicOr(&d.status[s], FER_ERR_ZERO_SUM);  // the reference mis-files sum 0 (F/moestimation.cpp:153)
+    if (k == 0) atomicAdd(&d.zero_cnt[s], 1);  // the reference mis-files sum 0: see k_sort_finish
 }
 
 // Payload of the sorted order + the two-level bucket index.  Record i opens every (sum, column tile) bin
 // after its predecessor's up to its own: kol2[bin] = i for those bins (lower bound of the bin in the sorted
 // order).  Gaps are short except at the ends of the sum range; long ones are filled by the whole wavefront.
+//
+// Bucket 0.  The reference's counting sort (F/moestimation.cpp:153-172) leaves bucket 0 out of its prefix sum:
+// with n0 positions of sum 0, every other bucket starts n0 places early (the sorted array is the other
+// positions from 0, its last n0 places keep what the previous picture left there), the k-th sum-0 position
+// is written to place n0 + k, where it replaces, or is replaced by, the regular occupant -- whichever the
+// scatter loop reaches later in arrival order --, bucket 0 reads as [0, 2 n0) and bucket 1 starts at 2 n0.
+// That layout is reproduced here for a stream with n0 > 0 (black areas in full-range content); the walk then
+// scans whole buckets by these rules (walk_buckets).  The index kol2 keeps describing the plain sorted order.
+__device__ __forceinline__ void sort_record(const FerDev &d, int s, uint32_t v, uint32_t *o)
+{
+    int tx = v >> 16, ty = v & 0xffff;
+    const uint32_t *r = (const uint32_t *)(d.feat0 + ((size_t)s * d.ysz + (size_t)ty * d.W + tx) * 6);
+    uint32_t a = r[0], b = r[1], c = r[2];  // k0|k1<<16, k2|k3<<16, k4
+    o[0] = v;
+    o[1] = (a >> 16) | (b << 16);
+    o[2] = (b >> 16) | (c << 16);
+}
+
 __global__ __launch_bounds__(256) void k_sort_finish(FerDev d, const uint32_t *skeys, const uint32_t *svals)
 {
     const int s = blockIdx.y;
@@ -195,20 +213,30 @@ __global__ __launch_bounds__(256) void k_sort_finish(FerDev d, const uint32_t *s
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = d.W * d.H;
     const int nb = 16384 * d.kt;
+    const int n0 = d.zero_cnt[s];
     uint32_t *kol2 = d.kol2 + (size_t)s * nb;
     const size_t g0 = (size_t)s * n;
     int gap_lo = 0, gap_hi = 0;  // bins [gap_lo, gap_hi) get value gval
     uint32_t gval = 0;
     if (i < n) {
-        uint32_t v = svals[g0 + i];
-        int tx = v >> 16, ty = v & 0xffff;
-        const uint32_t *r = (const uint32_t *)(d.feat0 + ((size_t)s * d.ysz + (size_t)ty * d.W + tx) * 6);
-        uint32_t a = r[0], b = r[1], c = r[2];  // k0|k1<<16, k2|k3<<16, k4
+        const uint32_t v = svals[g0 + i];
+        const int tx = v >> 16;
         d.sort_pos[g0 + i] = v;
-        uint32_t *o = d.sort_rec + (g0 + i) * 3;
-        o[0] = v;
-        o[1] = (a >> 16) | (b << 16);
-        o[2] = (b >> 16) | (c << 16);
+        if (n0 == 0) {
+            sort_record(d, s, v, d.sort_rec + (g0 + i) * 3);
+        } else if (i >= n0) {  // a regular position: n0 places early, unless the sum-0 position aimed there comes later
+            const int p = i - n0;
+            uint32_t w = v;
+            if (p >= n0 && p < 2 * n0) {
+                const uint32_t z = svals[g0 + p - n0];
+                const int bz = (int)(z >> 16) * d.H + (int)(z & 0xffff), bn = tx * d.H + (int)(v & 0xffff);
+                if (bz > bn) w = z;
+            }
+            sort_record(d, s, w, d.sort_rec + (g0 + p) * 3);
+        } else {  // a sum-0 position: place n0 + i, written here only where no regular position lands
+            const int p = n0 + i;
+            if (p >= n - n0 && p < n) sort_record(d, s, v, d.sort_rec + (g0 + p) * 3);
+        }
         int bin = (int)(skeys[g0 + i] & 0x7fff) * d.kt + (tx >> d.ktw_shift);
         int prev = -1;
         if (i > 0) {
@@ -415,6 +443,7 @@ void fer_launch_features(const FerDev &d, hipStream_t st)
 void fer_launch_sort(const FerDev &d, FerSortTmp &t, hipStream_t st)
 {
     int n = d.W * d.H;
+    hipMemsetAsync(d.zero_cnt, 0, sizeof(int) * d.S, st);
     hipLaunchKernelGGL(k_sort_keys, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.keys_in, t.vals_in);
     const int ntiles = (n + RS_TILE - 1) / RS_TILE;
     uint32_t *hist = (uint32_t *)t.tmp;

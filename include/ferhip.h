@@ -91,8 +91,8 @@ int ferhip_encode_streams(ferhip_ctx *c, const uint8_t *frames, int nframes, uin
 
 /* statistics of Starter::DohvatiStatistiku: brojTipova[5] per stream, accumulated */
 int ferhip_get_stats(ferhip_ctx *c, int *counts5_per_stream);
-/* sticky device error flags per stream (bit 0: unused, bit 1: an 8x8
- * block of the reference picture sums to 0, bit 2: RBSP buffer overflow) */
+/* sticky device error flags per stream (bits 0, 1: unused, bit 2: RBSP buffer overflow, bits 3, 4: decoder syntax
+ * error / unsupported syntax, bit 5: motion chain timeout) */
 int ferhip_status(ferhip_ctx *c, int *flags_per_stream);
 const char *ferhip_version(void);
 

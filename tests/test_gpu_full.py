@@ -148,6 +148,39 @@ def test_flat_areas_overflow_the_candidate_lists(pkg, fo, kind):
     assert streams[0] == ref and np.array_equal(rec[:, 0], ref_rec)
 
 
+@pytest.mark.parametrize("kind", ["bars", "quarter", "moving", "black_white"])
+def test_zero_sum_blocks_follow_the_reference_bucket_defect(pkg, fo, kind):
+    """Black (Y = 0) areas: 8x8 sums of 0 hit the reference's counting sort defect (bucket 0 is left out of the prefix
+    sum, F/moestimation.cpp:153) -- every other bucket sits early, sum-0 positions overwrite or are overwritten by
+    regular ones in arrival order, the end of the array keeps the previous picture's entries.  Reproduced, not refused."""
+    W, H, T = 352, 288, 5
+    frames = []
+    for t in range(T):
+        f = pkg.gen_frame(W, H, t, 31, 2).copy()
+        y = f[: W * H].reshape(H, W)
+        if kind == "bars":
+            y[:40] = 0
+            y[-40:] = 0
+        elif kind == "quarter":
+            y[: H // 2, : W // 2] = 0
+        elif kind == "moving":   # the black area grows and moves: the left-over end of the array changes every picture
+            y[16 * t: 16 * t + 64 + 8 * t, 32 + 24 * t: 200 + 8 * t] = 0
+        else:
+            y[:48] = 0
+            y[-48:] = 255
+        frames.append(f)
+    frames = np.stack(frames)[:, None]
+    g = pkg.FerHip(W, H, 1, qp=16, window=32, maxdiff=3, intra_every=30)
+    streams, rec = g.encode_streams(frames, want_recon=True)
+    assert g.status() == [0]
+    g.close()
+    o = fo.Oracle(W, H, qp=16, window=32, maxdiff=3, intra_every=30)
+    ref, ref_rec = o.encode_stream(frames[:, 0])
+    o.close()
+    assert np.array_equal(rec[:, 0], ref_rec)
+    assert streams[0] == ref
+
+
 def test_scene_cut_forces_idr(pkg, fo):
     """selectNALUnitType: frame SAD above 16/pixel turns a P picture into IDR (F/ref_frames.cpp:210-228)."""
     W, H = 176, 144

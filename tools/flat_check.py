@@ -10,7 +10,7 @@ import fo_py
 pkg = load_pkg()
 W, H, T = (int(sys.argv[1]), int(sys.argv[2]), 3) if len(sys.argv) > 2 else (352, 288, 3)
 import time
-for name in ("flat", "half", "bars"):
+for name in ("flat", "half", "bars", "black_bars", "black_quarter", "black_white"):
     frames = []
     for t in range(T):
         f = pkg.gen_frame(W, H, t, 77, 2).copy()
@@ -19,9 +19,17 @@ for name in ("flat", "half", "bars"):
             y[:] = 128
         elif name == "half":
             y[:, : W // 2] = 100
-        else:
+        elif name == "bars":
             y[:32] = 16
             y[-32:] = 16
+        elif name == "black_bars":      # sum-0 blocks: the reference's bucket-0 defect
+            y[:40] = 0
+            y[-40:] = 0
+        elif name == "black_quarter":
+            y[: H // 2, : W // 2] = 0
+        else:
+            y[:48] = 0
+            y[-48:] = 255
         frames.append(f)
     frames = np.stack(frames)[:, None]
     g = pkg.FerHip(W, H, 1, qp=20, window=32, maxdiff=3, intra_every=30)

@@ -21,6 +21,18 @@ for it in range(N):
     still = rng.random() < 0.25  # static content: P_Skip heavy
     frames = np.stack([np.stack([pkg.gen_frame(W, H, 0 if still else t, seeds[s], noise if not still else 0) for s in range(S)])
                        for t in range(T)])
+    shape = rng.choice(["none", "none", "flat_box", "black_box", "black_rows"])
+    if shape != "none" and W >= 64 and H >= 48:
+        for t in range(T):
+            for s_ in range(S):
+                y = frames[t, s_][: W * H].reshape(H, W)
+                x0, y0 = rng.randrange(0, W // 2), rng.randrange(0, H // 2)
+                if shape == "flat_box":
+                    y[y0: y0 + H // 3, x0: x0 + W // 2] = rng.choice([16, 128, 235])
+                elif shape == "black_box":
+                    y[y0: y0 + H // 4, x0: x0 + W // 3] = 0
+                else:
+                    y[: 8 * rng.randrange(2, 5)] = 0
     g = pkg.FerHip(W, H, S, **cfg)
     streams, rec = g.encode_streams(frames, want_recon=True)
     st = g.status()
@@ -55,5 +67,5 @@ for it in range(N):
     ok &= not why
     if not ok:
         bad += 1
-    print(("ok  " if ok else "FAIL"), W, H, T, S, cfg, "noise", noise, "still", still, "status", st, " ".join(why), flush=True)
+    print(("ok  " if ok else "FAIL"), W, H, T, S, cfg, "noise", noise, "still", still, shape, "status", st, " ".join(why), flush=True)
 print("failures:", bad, "of", N)
