@@ -109,20 +109,21 @@ __global__ __launch_bounds__(64) void k_cavlc(FerDev d)
 }
 
 // per-stream exclusive scan of the nmb+1 sizes, offset by the slice header, which this kernel
-// also writes (one block of 1024 threads per stream)
-__global__ __launch_bounds__(1024) void k_bits_scan(FerDev d)
+// also writes (one block of 256 threads per stream: a small block finds a free slot sooner when another context's
+// kernels fill the GPU)
+__global__ __launch_bounds__(256) void k_bits_scan(FerDev d)
 {
-    __shared__ unsigned part[1024];
+    __shared__ unsigned part[256];
     const int s = blockIdx.x, tid = threadIdx.x;
     uint32_t *sizes = d.mb_bits + (size_t)s * (d.nmb + 1);
     const int n = d.nmb + 1;
-    const int per = (n + 1023) / 1024;
+    const int per = (n + 255) / 256;
     int b0 = tid * per, b1 = min(b0 + per, n);
     unsigned sum = 0;
     for (int i = b0; i < b1; i++) sum += sizes[i];
     part[tid] = sum;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
+    for (int o = 1; o < 256; o <<= 1) {
         unsigned v = tid >= o ? part[tid - o] : 0;
         __syncthreads();
         part[tid] += v;
@@ -149,6 +150,6 @@ void fer_launch_cavlc(const FerDev &d, hipStream_t st)
     hipMemsetAsync(d.bits, 0, d.bits_cap_words * 4 * (size_t)d.S, st);
     dim3 g((d.nmb + 1 + 63) / 64, d.S);
     hipLaunchKernelGGL(k_cavlc<false>, g, dim3(64), 0, st, d);
-    hipLaunchKernelGGL(k_bits_scan, dim3(d.S), dim3(1024), 0, st, d);
+    hipLaunchKernelGGL(k_bits_scan, dim3(d.S), dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_cavlc<true>, g, dim3(64), 0, st, d);
 }

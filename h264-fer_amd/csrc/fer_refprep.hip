@@ -297,20 +297,20 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(FerDev d, const uint32_t
     hist[((size_t)s * 256 + tid) * ntiles + tile] = h[tid];  // digit-major: the scan order is the output order
 }
 
-__global__ __launch_bounds__(1024) void k_rs_scan(FerDev d, uint32_t *hist, int ntiles)
+__global__ __launch_bounds__(256) void k_rs_scan(FerDev d, uint32_t *hist, int ntiles)
 {
-    __shared__ unsigned part[1024];
+    __shared__ unsigned part[256];
     const int s = blockIdx.x, tid = threadIdx.x;
     if (d.hdr[s * 4 + 3] != 0) return;
     uint32_t *h = hist + (size_t)s * 256 * ntiles;
     const int n = 256 * ntiles;
-    const int per = (n + 1023) / 1024;
+    const int per = (n + 255) / 256;
     const int b0 = min(tid * per, n), b1 = min(b0 + per, n);
     unsigned sum = 0;
     for (int i = b0; i < b1; i++) sum += h[i];
     part[tid] = sum;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
+    for (int o = 1; o < 256; o <<= 1) {
         unsigned v = tid >= o ? part[tid - o] : 0;
         __syncthreads();
         part[tid] += v;
@@ -451,7 +451,7 @@ void fer_launch_sort(const FerDev &d, FerSortTmp &t, hipStream_t st)
     for (int pass = 0; pass < 2; pass++) {  // sum bits 0-7, then 8-14
         const int shift = pass * 8;
         hipLaunchKernelGGL(k_rs_hist, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, ki, hist, ntiles, shift);
-        hipLaunchKernelGGL(k_rs_scan, dim3(d.S), dim3(1024), 0, st, d, hist, ntiles);
+        hipLaunchKernelGGL(k_rs_scan, dim3(d.S), dim3(256), 0, st, d, hist, ntiles);
         hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, ki, vi, ko, vo, hist, ntiles, shift);
         uint32_t *x = ki;
         ki = ko;
