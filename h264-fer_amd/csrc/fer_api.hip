@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <utility>
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -1038,6 +1039,69 @@ static void split_stream(const uint8_t *s, size_t n, std::vector<NalRef> &out)
     }
 }
 
+struct DecArena {
+    void *dev = nullptr;
+    size_t bytes = 0;
+    uint8_t *d_rbsp = nullptr, *h_rbsp = nullptr;  // slices of a window: device buffer and pinned staging
+    size_t rbsp_cap = 0;
+    bool busy = false, cached = false;
+};
+static DecArena g_dec_arena;
+static std::mutex g_dec_arena_mu;
+static uint8_t *g_null_u8 = nullptr;
+static size_t g_null_sz = 0;
+static void dec_arena_free(DecArena *a)
+{
+    if (a->dev) hipFree(a->dev);
+    if (a->d_rbsp) hipFree(a->d_rbsp);
+    if (a->h_rbsp) hipHostFree(a->h_rbsp);
+    a->dev = nullptr;
+    a->d_rbsp = a->h_rbsp = nullptr;
+    a->bytes = a->rbsp_cap = 0;
+}
+static DecArena *dec_arena_acquire(size_t need)
+{
+    DecArena *a;
+    {
+        std::lock_guard<std::mutex> lk(g_dec_arena_mu);
+        if (!g_dec_arena.busy) {
+            a = &g_dec_arena;
+            a->busy = true;
+            a->cached = true;
+        } else {
+            a = new DecArena();
+            a->busy = true;
+        }
+    }
+    if (a->bytes < need) {
+        if (a->dev) hipFree(a->dev);
+        a->dev = nullptr;
+        a->bytes = 0;
+        if (hipMalloc(&a->dev, need) != hipSuccess) {
+            a->dev = nullptr;
+            std::lock_guard<std::mutex> lk(g_dec_arena_mu);
+            if (a->cached)
+                a->busy = false;
+            else
+                delete a;
+            return nullptr;
+        }
+        a->bytes = need;
+    }
+    return a;
+}
+static void dec_arena_release(DecArena *a)
+{
+    if (!a) return;
+    if (a->cached) {
+        std::lock_guard<std::mutex> lk(g_dec_arena_mu);
+        a->busy = false;
+    } else {
+        dec_arena_free(a);
+        delete a;
+    }
+}
+
 // decode() for S Annex-B streams side by side.  All streams must carry the same picture size.
 // out: host [T][S][W*H*3/2] (T = max_pictures); pictures[s] = pictures decoded of stream s.
 extern "C" int ferhip_decode_streams(const uint8_t *const *streams, const size_t *lens, int S, uint8_t *out,
@@ -1099,34 +1163,43 @@ extern "C" int ferhip_decode_streams(const uint8_t *const *streams, const size_t
     const size_t per_pic = nm * (4 + 16 + 2 + 24 + 16 + 16 + 1 + FER_LEVELS * 2 + 1 + 1);
     size_t TWmax = std::min<size_t>(std::max<size_t>((size_t)48e9 / per_pic, 1), 256);
     TWmax = std::max<size_t>(std::min(TWmax, T), 1);
-    std::vector<void *> wal;
+    // The window's buffers are carved from one arena that is kept between calls (releasing tens of GB costs more
+    // than a window's reconstruction); a second call running at the same time gets its own.
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t sizes[16] = {TWmax * nm * 4, TWmax * nm * 16, TWmax * nm * 2, TWmax * nm * 24, TWmax * nm * 16, TWmax * nm * 16,
+                              TWmax * nm, TWmax * nm * FER_LEVELS * 2, TWmax * nm, TWmax * nm, TWmax * S * 16, TWmax * S * 16,
+                              TWmax * S * 16, TWmax * S * 256, TWmax * S * 256, TWmax * S * 24};
+    size_t need = 0;
+    for (size_t b : sizes) need += up(b) + 256;
+    DecArena *ar = dec_arena_acquire(need);
+    uint8_t *base = ar ? (uint8_t *)ar->dev : nullptr;
+    size_t off = 0;
     auto wmalloc = [&](size_t bytes) -> void * {
-        void *v = nullptr;
-        if (hipMalloc(&v, bytes + 256) != hipSuccess) return nullptr;
-        wal.push_back(v);
+        if (!base) return nullptr;
+        void *v = base + off;
+        off += up(bytes) + 256;
         return v;
     };
     DecBatch B;
-    B.mb_type = (int *)wmalloc(TWmax * nm * 4);
-    B.mv = (short *)wmalloc(TWmax * nm * 16);
-    B.cbp = (uint8_t *)wmalloc(TWmax * nm * 2);
-    B.tc = (uint8_t *)wmalloc(TWmax * nm * 24);
-    B.i4mode = (uint8_t *)wmalloc(TWmax * nm * 16);
-    B.i4flag = (uint8_t *)wmalloc(TWmax * nm * 16);
-    B.chroma_mode = (uint8_t *)wmalloc(TWmax * nm);
-    B.levels = (int16_t *)wmalloc(TWmax * nm * FER_LEVELS * 2);
-    B.dec_qp = (uint8_t *)wmalloc(TWmax * nm);
-    B.carry = (uint8_t *)wmalloc(TWmax * nm);
-    B.hdr = (uint32_t *)wmalloc(TWmax * S * 16);
-    B.state = (int *)wmalloc(TWmax * S * 16);
-    B.summ = (int *)wmalloc(TWmax * S * 16);
-    B.cac_in = (int16_t *)wmalloc(TWmax * S * 256);
-    B.cac_out = (int16_t *)wmalloc(TWmax * S * 256);
-    uint32_t *d_info = (uint32_t *)wmalloc(TWmax * S * 24);
-    uint8_t *d_rbsp = nullptr, *h_rbsp = nullptr;  // all slices of a window: device buffer and pinned staging
-    size_t d_rbsp_cap = 0;
-    bool alloc_ok = B.mb_type && B.mv && B.cbp && B.tc && B.i4mode && B.i4flag && B.chroma_mode && B.levels && B.dec_qp &&
-                    B.carry && B.hdr && B.state && B.summ && B.cac_in && B.cac_out && d_info;
+    B.mb_type = (int *)wmalloc(sizes[0]);
+    B.mv = (short *)wmalloc(sizes[1]);
+    B.cbp = (uint8_t *)wmalloc(sizes[2]);
+    B.tc = (uint8_t *)wmalloc(sizes[3]);
+    B.i4mode = (uint8_t *)wmalloc(sizes[4]);
+    B.i4flag = (uint8_t *)wmalloc(sizes[5]);
+    B.chroma_mode = (uint8_t *)wmalloc(sizes[6]);
+    B.levels = (int16_t *)wmalloc(sizes[7]);
+    B.dec_qp = (uint8_t *)wmalloc(sizes[8]);
+    B.carry = (uint8_t *)wmalloc(sizes[9]);
+    B.hdr = (uint32_t *)wmalloc(sizes[10]);
+    B.state = (int *)wmalloc(sizes[11]);
+    B.summ = (int *)wmalloc(sizes[12]);
+    B.cac_in = (int16_t *)wmalloc(sizes[13]);
+    B.cac_out = (int16_t *)wmalloc(sizes[14]);
+    uint32_t *d_info = (uint32_t *)wmalloc(sizes[15]);
+    uint8_t *&d_rbsp = ar ? ar->d_rbsp : g_null_u8, *&h_rbsp = ar ? ar->h_rbsp : g_null_u8;  // all slices of a window
+    size_t &d_rbsp_cap = ar ? ar->rbsp_cap : g_null_sz;
+    bool alloc_ok = base != nullptr;
     const double t_alloc = now();
     std::vector<uint32_t> info, hdr;
     std::vector<char> anyP, anyAny;
@@ -1260,9 +1333,7 @@ extern "C" int ferhip_decode_streams(const uint8_t *const *streams, const size_t
 #endif
     hipStreamSynchronize(c->st);
     const double t_free0 = now();
-    if (d_rbsp) hipFree(d_rbsp);
-    if (h_rbsp) hipHostFree(h_rbsp);
-    for (void *v : wal) hipFree(v);
+    dec_arena_release(ar);
     ferhip_destroy(c);
     if (verbose) fprintf(stderr, "ferhip_decode_streams: release %.3f s, total %.3f s\n", now() - t_free0, now() - t_start);
     return rc;
