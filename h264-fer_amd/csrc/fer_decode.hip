@@ -450,8 +450,13 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
     }
     uint8_t *carry = B.carry + pic * d.nmb;
     int *st = B.state + pic * 4, *summ = B.summ + pic * 4;
-    const int stype = (int)info[2];
-    if (info[0] == 0) {  // no picture for this stream at this step
+    // the slice parameters are the same in every lane: scalar registers, so that everything derived from them
+    // (bit position, window, QP) stays on the scalar unit
+    const unsigned i_size = (unsigned)__builtin_amdgcn_readfirstlane((int)info[0]);
+    const unsigned i_pos = (unsigned)__builtin_amdgcn_readfirstlane((int)info[1]);
+    const int stype = __builtin_amdgcn_readfirstlane((int)info[2]);
+    const unsigned i_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)info[4]), i_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)info[5]);
+    if (i_size == 0) {  // no picture for this stream at this step
         if (lane == 0) {
             st[1] = 0;
             summ[0] = summ[3] = 0;
@@ -459,8 +464,8 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
         return;
     }
     DecBits b;
-    db_open(b, B.rbsp + (((size_t)info[5] << 32) | info[4]), info[0], info[1]);
-    int QPy = (int)info[3];
+    db_open(b, B.rbsp + (((size_t)i_hi << 32) | i_lo), i_size, i_pos);
+    int QPy = __builtin_amdgcn_readfirstlane((int)info[3]);
     int *mbt = d.mb_type + (size_t)s * d.nmb;
     short *mvs = d.mv + (size_t)s * d.nmb * 8;
     int mb_qp_delta = 0;  // the inherited value is added by k_dec_patch
