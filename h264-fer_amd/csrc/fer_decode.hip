@@ -249,6 +249,7 @@ __device__ int dec_block(DecBits &b, const DecLutsLds *L, int16_t *coef, int max
         db_skip(b, e >> 8);
         zerosLeft = (int)(e & 0xff);
     }
+    unsigned long long runs = 0;  // run_before of coefficient j in bits 4j..4j+3 (scalar registers, no LDS round trips)
     for (int j = 0; j < TotalCoeff - 1; j++) {
         int rb = 0;
         if (zerosLeft > 0) {
@@ -268,17 +269,23 @@ __device__ int dec_block(DecBits &b, const DecLutsLds *L, int16_t *coef, int max
                 rb = (int)(e & 0xff);
             }
         }
-        rn[j] = (uint8_t)rb;
+        runs |= (unsigned long long)(rb & 15) << (4 * j);
         zerosLeft -= rb;
     }
-    rn[TotalCoeff - 1] = (uint8_t)max(zerosLeft, 0);
+    runs |= (unsigned long long)(max(zerosLeft, 0) & 15) << (4 * (TotalCoeff - 1));
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    int coeffNum = -1;
-    for (int i = TotalCoeff - 1; i >= 0; i--) {
-        coeffNum += __builtin_amdgcn_readfirstlane((int)rn[i]) + 1;
-        if (coeffNum >= 0 && coeffNum < maxNumCoeff) coef[coeffNum] = lvl[i];
+    {  // placement, one coefficient per lane: position of coefficient i = sum over k >= i of (run_k + 1), minus 1
+        const int i = (int)(threadIdx.x & 63);
+        if (i < TotalCoeff) {
+            unsigned long long x = runs >> (4 * i);
+            unsigned long long sm = (x & 0x0f0f0f0f0f0f0f0full) + ((x >> 4) & 0x0f0f0f0f0f0f0f0full);
+            unsigned s32 = (unsigned)sm + (unsigned)(sm >> 32);
+            int pos = (TotalCoeff - i) - 1 + (int)((s32 * 0x01010101u) >> 24);
+            if (pos < maxNumCoeff) coef[pos] = lvl[i];
+        }
     }
+    (void)rn;
     return TotalCoeff;
 }
 
