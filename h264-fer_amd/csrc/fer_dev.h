@@ -101,8 +101,7 @@ struct DecBatch {
     const uint32_t *info; // [TW][S][6]: bytes, first bit of slice_data, slice_type % 5, SliceQPy, byte offset lo, hi
 };
 
-#define FER_ERR_ST2_OVERFLOW 1
-#define FER_ERR_ZERO_SUM 2
+// bits 0 and 1 (stage-2 list overflow, zero-sum blocks) are no longer raised: both cases are handled exactly
 #define FER_ERR_BITS_OVERFLOW 4
 #define FER_ERR_DEC_SYNTAX 8
 #define FER_ERR_DEC_UNSUPPORTED 16
