@@ -160,12 +160,14 @@ def main():
     value = total_mbs / dt
 
     # roofline of the dominant kernel (by accumulated device time; every profiled phase is one kernel, except
-    # "sort" = k_sort_keys + radix sort + k_sort_finish and "cavlc" = size + scan + emit)
+    # "sort" = the six launches of the two radix passes and "cavlc" = size + scan + emit)
     p_pictures = (GOP - 1) * args.steps
     KERNELS = {  # phase -> (kernel, algorithmic bytes per macroblock, pictures it runs on)
         "interp": ("k_interp", 256 + 16 * 256, p_pictures),
         "features": ("k_features", 16 * 256 + 256 * (192 + 12), p_pictures),
-        "sort": ("k_sort_keys+radix_sort+k_sort_finish", 256 * (2 + 8) + 3 * 256 * 16 + 256 * (8 + 12 + 16), p_pictures),
+        "sort_keys": ("k_sort_keys", 256 * (2 + 8), p_pictures),
+        "sort": ("k_rs_hist+k_rs_scan+k_rs_scatter (two radix passes)", 2 * 256 * (4 + 8 + 8), p_pictures),
+        "sort_finish": ("k_sort_finish", 256 * (8 + 12 + 16), p_pictures),
         "me_pre": ("k_me_pre", ME_BYTES_PER_MB, p_pictures),
         "me_walk": ("k_me_walk", ME_BYTES_PER_MB, p_pictures),
         "me_resolve": ("k_me_resolve", ME_BYTES_PER_MB, p_pictures),

@@ -564,8 +564,16 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
                 fer_launch_features(d, c->st);
             }
             {
+                ProfScope ps(c, FERHIP_PH_SORT_KEYS, 1);
+                fer_launch_sort_keys(d, c->sort, c->st);
+            }
+            {
                 ProfScope ps(c, FERHIP_PH_SORT, 1);
-                fer_launch_sort(d, c->sort, c->st);
+                fer_launch_sort_radix(d, c->sort, c->st);
+            }
+            {
+                ProfScope ps(c, FERHIP_PH_SORT_FINISH, 1);
+                fer_launch_sort_finish(d, c->sort, c->st);
             }
         }
         {

@@ -14,6 +14,9 @@ void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStr
 void fer_launch_interp(const FerDev &d, hipStream_t st);
 void fer_launch_features(const FerDev &d, hipStream_t st);
 void fer_launch_sort(const FerDev &d, FerSortTmp &t, hipStream_t st);
+void fer_launch_sort_keys(const FerDev &d, FerSortTmp &t, hipStream_t st);
+void fer_launch_sort_radix(const FerDev &d, FerSortTmp &t, hipStream_t st);
+void fer_launch_sort_finish(const FerDev &d, FerSortTmp &t, hipStream_t st);
 void fer_launch_me_walk(const FerDev &d, hipStream_t st);
 void fer_launch_frame_sad(const FerDev &d, hipStream_t st);
 void fer_launch_me_pre(const FerDev &d, hipStream_t st);

@@ -440,11 +440,17 @@ void fer_launch_features(const FerDev &d, hipStream_t st)
     hipLaunchKernelGGL(k_features, dim3((unsigned)((fw + 3) / 4)), dim3(256), 0, st, d);
 }
 
-void fer_launch_sort(const FerDev &d, FerSortTmp &t, hipStream_t st)
+// the sort in three profiled steps: keys, the two radix passes, payload + bucket index
+void fer_launch_sort_keys(const FerDev &d, FerSortTmp &t, hipStream_t st)
 {
     int n = d.W * d.H;
     hipMemsetAsync(d.zero_cnt, 0, sizeof(int) * d.S, st);
     hipLaunchKernelGGL(k_sort_keys, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.keys_in, t.vals_in);
+}
+
+void fer_launch_sort_radix(const FerDev &d, FerSortTmp &t, hipStream_t st)
+{
+    int n = d.W * d.H;
     const int ntiles = (n + RS_TILE - 1) / RS_TILE;
     uint32_t *hist = (uint32_t *)t.tmp;
     uint32_t *ki = t.keys_in, *vi = t.vals_in, *ko = t.keys_out, *vo = t.vals_out;
@@ -460,8 +466,20 @@ void fer_launch_sort(const FerDev &d, FerSortTmp &t, hipStream_t st)
         vi = vo;
         vo = x;
     }
+}
+
+void fer_launch_sort_finish(const FerDev &d, FerSortTmp &t, hipStream_t st)
+{
+    int n = d.W * d.H;
     // after two passes the sorted pairs are back in keys_in / vals_in
-    hipLaunchKernelGGL(k_sort_finish, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, ki, vi);
+    hipLaunchKernelGGL(k_sort_finish, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.keys_in, t.vals_in);
+}
+
+void fer_launch_sort(const FerDev &d, FerSortTmp &t, hipStream_t st)
+{
+    fer_launch_sort_keys(d, t, st);
+    fer_launch_sort_radix(d, t, st);
+    fer_launch_sort_finish(d, t, st);
 }
 
 void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStream_t st)

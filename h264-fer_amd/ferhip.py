@@ -183,7 +183,8 @@ class FerHip:
             raise FerHipError(f"ferhip_read_buffer({name}) returned {got}, expected {out.nbytes}")
         return out
 
-    PHASES = ("interp", "me_pre", "me_resolve", "p_resid", "intra", "cavlc", "frame_sad", "features", "sort", "me_walk")
+    PHASES = ("interp", "me_pre", "me_resolve", "p_resid", "intra", "cavlc", "frame_sad", "features", "sort", "me_walk",
+              "sort_keys", "sort_finish")
     NPHASE = 12
 
     def profile(self, enable=True):

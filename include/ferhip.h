@@ -107,8 +107,10 @@ const char *ferhip_version(void);
 #define FERHIP_PH_CAVLC 5      /* size + scan + emit */
 #define FERHIP_PH_FRAME_SAD 6
 #define FERHIP_PH_FEATURES 7   /* k_features: box features of every position and plane */
-#define FERHIP_PH_SORT 8       /* k_sort_keys + radix sort + k_sort_finish (bucket index) */
+#define FERHIP_PH_SORT 8       /* the two radix passes: k_rs_hist, k_rs_scan, k_rs_scatter, each twice */
 #define FERHIP_PH_ME_WALK 9    /* k_me_walk: stage-2 candidate sets */
+#define FERHIP_PH_SORT_KEYS 10   /* k_sort_keys */
+#define FERHIP_PH_SORT_FINISH 11 /* k_sort_finish: payload of the sorted order + bucket index */
 #define FERHIP_NPHASE 12
 int ferhip_profile(ferhip_ctx *c, int enable);
 int ferhip_get_profile(ferhip_ctx *c, double *ms, long *launches, int reset);

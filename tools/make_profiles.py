@@ -97,7 +97,7 @@ def g(prefix):
 tj = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 tools/quick_hd.py 16 2`, see "
                  "r01_hbm_traffic_pmc.md; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch divided by the macroblocks one "
                  "dispatch processes; the x2 FETCH correction of MI355X_MICROARCH.md is calibrated for wide coalesced reads only",
-      "bytes_per_mb": {"interp": round(g("k_interp")), "features": round(g("k_features")), "sort": round(g("k_sort") + g("k_rs")),
+      "bytes_per_mb": {"interp": round(g("k_interp")), "features": round(g("k_features")), "sort_keys": round(g("k_sort_keys")), "sort": round(g("k_rs")), "sort_finish": round(g("k_sort_finish")),
                        "me_pre": round(g("k_me_pre")), "me_walk": round(g("k_me_walk")), "me_resolve": round(g("k_me_resolve")),
                        "p_resid": round(g("k_p_resid")), "intra": round(g("k_intra")),
                        "cavlc": round(g("k_cavlc") + g("k_bits"))}}
