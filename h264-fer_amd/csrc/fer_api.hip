@@ -24,6 +24,7 @@
         }                                                                                             \
     } while (0)
 
+#define FER_HDR_SLOTS 8
 struct StreamState {  // slice-level state of one stream (globals `shd`, statics of RBSP_encode)
     int frame_num, poc_lsb, idr_pic_id, first_idr_done, frames_done, have_dpb;
 };
@@ -38,7 +39,10 @@ struct ferhip_ctx {
     std::vector<StreamState> ss;
     std::vector<void *> allocs;
     FerSortTmp sort;
-    uint32_t *h_hdr;       // pinned [S][4]
+    uint32_t *h_hdr;       // pinned [S][4]: the slot of the header ring that the next picture fills
+    uint32_t *h_hdr_ring;  // pinned [FER_HDR_SLOTS][S][4]; a pinned source is read when the copy executes, not when it is
+    hipEvent_t hdr_ev[8];  // enqueued, so a slot is rewritten only after the copy that last used it has run
+    int hdr_slot;
     uint32_t *h_len;       // pinned [S]
     int *h_status;         // pinned [S]
     unsigned long long *h_sad;
@@ -115,7 +119,6 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
 {
     if (!out || !p || W <= 0 || H <= 0 || (W & 15) || (H & 15) || S <= 0 || W > 16384 || H > 16384) return FERHIP_E_ARG;
     if (p->qp < 0 || p->qp > 51 || p->window < 16 || p->intra_every <= 0) return FERHIP_E_ARG;
-    if (p->basic) return FERHIP_E_UNSUP;  // BasicInterEncoding's extra exhaustive pass is not implemented
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         fprintf(stderr, "ferhip: no HIP device; the hot path has no CPU fallback\n");
@@ -123,6 +126,13 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     }
     ferhip_ctx *c = new ferhip_ctx();
     memset(&c->d, 0, sizeof c->d);
+    c->st = c->st_hi = nullptr;
+    c->ev_a = c->ev_b = nullptr;
+    c->h_hdr = c->h_hdr_ring = c->h_len = nullptr;
+    c->h_status = nullptr;
+    c->h_sad = nullptr;
+    for (int i = 0; i < FER_HDR_SLOTS; i++) c->hdr_ev[i] = nullptr;
+    c->planes[0] = c->planes[1] = nullptr;
     c->p = *p;
     FerDev &d = c->d;
     d.W = W;
@@ -137,18 +147,20 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     d.qpc = k_qpc[p->qp];  // chroma_qp_index_offset == 0 (F/headers_and_parameter_sets.cpp:490)
     d.window = p->window;
     d.maxdiff_set = p->maxdiff;
-    d.basic = 0;
+    d.basic = p->basic ? 1 : 0;
     d.dbg = getenv("FER_DBG") ? atoi(getenv("FER_DBG")) : 0;
     d.ysz = (size_t)W * H;
     d.csz = d.ysz / 4;
-    CK(hipGetDevice(&c->device));
     {
-        int lo = 0, hi = 0;
-        CK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // numerically lower = higher priority
-        CK(hipStreamCreateWithPriority(&c->st, hipStreamNonBlocking, lo));
-        CK(hipStreamCreateWithPriority(&c->st_hi, hipStreamNonBlocking, hi));
-        CK(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
-        CK(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
+        int lo = 0, hi = 0;  // numerically lower = higher priority
+        if (hipGetDevice(&c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&c->st, hipStreamNonBlocking, lo) != hipSuccess ||
+            hipStreamCreateWithPriority(&c->st_hi, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess) {
+            ferhip_destroy(c);
+            return FERHIP_E_HIP;
+        }
     }
     size_t fsz = d.ysz * 3 / 2;
     int rc = 0;
@@ -207,10 +219,20 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
         ferhip_destroy(c);
         return FERHIP_E_HIP;
     }
-    CK(hipHostMalloc((void **)&c->h_hdr, sizeof(uint32_t) * 4 * S));
-    CK(hipHostMalloc((void **)&c->h_len, sizeof(uint32_t) * S));
-    CK(hipHostMalloc((void **)&c->h_status, sizeof(int) * S));
-    CK(hipHostMalloc((void **)&c->h_sad, sizeof(unsigned long long) * S));
+    if (hipHostMalloc((void **)&c->h_hdr_ring, sizeof(uint32_t) * 4 * S * FER_HDR_SLOTS) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_len, sizeof(uint32_t) * S) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_status, sizeof(int) * S) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_sad, sizeof(unsigned long long) * S) != hipSuccess) {
+        ferhip_destroy(c);
+        return FERHIP_E_HIP;
+    }
+    for (int i = 0; i < FER_HDR_SLOTS; i++)
+        if (hipEventCreateWithFlags(&c->hdr_ev[i], hipEventDisableTiming) != hipSuccess) {
+            ferhip_destroy(c);
+            return FERHIP_E_HIP;
+        }
+    c->hdr_slot = 0;
+    c->h_hdr = c->h_hdr_ring;
     c->ss.assign(S, StreamState{0, 0, 0, 0, 0, 0});
     c->types.assign(S, 2);
     c->cur_set = 0;
@@ -221,7 +243,10 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     bind_planes(c);
     // the buffers were cleared on the null stream, which the context's non-blocking streams do not wait for: without
     // this the clearing of a large buffer can land after the first picture's kernels have written into it
-    CK(hipDeviceSynchronize());
+    if (hipDeviceSynchronize() != hipSuccess) {
+        ferhip_destroy(c);
+        return FERHIP_E_HIP;
+    }
     *out = c;
     return 0;
 }
@@ -230,17 +255,19 @@ extern "C" void ferhip_destroy(ferhip_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    hipStreamSynchronize(c->st);
-    hipStreamSynchronize(c->st_hi);
+    if (c->st) hipStreamSynchronize(c->st);
+    if (c->st_hi) hipStreamSynchronize(c->st_hi);
     for (void *p : c->allocs) hipFree(p);
-    if (c->h_hdr) hipHostFree(c->h_hdr);
+    if (c->h_hdr_ring) hipHostFree(c->h_hdr_ring);
+    for (int i = 0; i < FER_HDR_SLOTS; i++)
+        if (c->hdr_ev[i]) hipEventDestroy(c->hdr_ev[i]);
     if (c->h_len) hipHostFree(c->h_len);
     if (c->h_status) hipHostFree(c->h_status);
     if (c->h_sad) hipHostFree(c->h_sad);
-    hipStreamDestroy(c->st);
-    hipStreamDestroy(c->st_hi);
-    hipEventDestroy(c->ev_a);
-    hipEventDestroy(c->ev_b);
+    if (c->st) hipStreamDestroy(c->st);
+    if (c->st_hi) hipStreamDestroy(c->st_hi);
+    if (c->ev_a) hipEventDestroy(c->ev_a);
+    if (c->ev_b) hipEventDestroy(c->ev_b);
     delete c;
 }
 
@@ -494,6 +521,22 @@ static void build_header(ferhip_ctx *c, int s, int nal_type)
     c->types[s] = slice_type;
 }
 
+// Start filling the next slot of the header ring (waits for the copy that used it FER_HDR_SLOTS pictures ago) ...
+static int hdr_begin(ferhip_ctx *c)
+{
+    c->hdr_slot = (c->hdr_slot + 1) % FER_HDR_SLOTS;
+    CK(hipEventSynchronize(c->hdr_ev[c->hdr_slot]));
+    c->h_hdr = c->h_hdr_ring + (size_t)c->hdr_slot * 4 * c->d.S;
+    return 0;
+}
+// ... and send it
+static int hdr_upload(ferhip_ctx *c)
+{
+    CK(hipMemcpyAsync(c->d.hdr, c->h_hdr, sizeof(uint32_t) * 4 * c->d.S, hipMemcpyHostToDevice, c->st));
+    CK(hipEventRecord(c->hdr_ev[c->hdr_slot], c->st));
+    return 0;
+}
+
 // selectNALUnitType, F/ref_frames.cpp:185-234: nt[s] in = request (AUTO / IDR / SLICE), out = decision
 static int decide_types(ferhip_ctx *c, const int *nal_type, std::vector<int> &nt)
 {
@@ -545,13 +588,14 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
     int rc0 = decide_types(c, nal_type, nt);
     if (rc0) return rc0;
     bool anyP = false, anyI = false;
+    if (hdr_begin(c)) return FERHIP_E_HIP;
     for (int s = 0; s < S; s++) {
         build_header(c, s, nt[s]);
         if (nal_type) nal_type[s] = nt[s];
         anyP |= c->types[s] == 0;
         anyI |= c->types[s] == 2;
     }
-    CK(hipMemcpyAsync(d.hdr, c->h_hdr, sizeof(uint32_t) * 4 * S, hipMemcpyHostToDevice, c->st));
+    if (hdr_upload(c)) return FERHIP_E_HIP;
     const int ndiag = d.mbw + 2 * (d.mbh - 1);
     if (anyP) {
         if (!c->refprep_valid) {
@@ -563,17 +607,20 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
                 ProfScope ps(c, FERHIP_PH_FEATURES, 1);
                 fer_launch_features(d, c->st);
             }
-            {
-                ProfScope ps(c, FERHIP_PH_SORT_KEYS, 1);
-                fer_launch_sort_keys(d, c->sort, c->st);
-            }
-            {
-                ProfScope ps(c, FERHIP_PH_SORT, 1);
-                fer_launch_sort_radix(d, c->sort, c->st);
-            }
-            {
-                ProfScope ps(c, FERHIP_PH_SORT_FINISH, 1);
-                fer_launch_sort_finish(d, c->sort, c->st);
+            // BasicInterEncoding never walks the buckets (F/moestimation.cpp:470): the sorted order is not built
+            if (!d.basic) {
+                {
+                    ProfScope ps(c, FERHIP_PH_SORT_KEYS, 1);
+                    fer_launch_sort_keys(d, c->sort, c->st);
+                }
+                {
+                    ProfScope ps(c, FERHIP_PH_SORT, 1);
+                    fer_launch_sort_radix(d, c->sort, c->st);
+                }
+                {
+                    ProfScope ps(c, FERHIP_PH_SORT_FINISH, 1);
+                    fer_launch_sort_finish(d, c->sort, c->st);
+                }
             }
         }
         {
@@ -599,6 +646,7 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
         }
         {
             ProfScope ps(c, FERHIP_PH_P_RESID, 1);
+            fer_launch_basic_stat(d, c->st);  // BasicInterEncoding only: brojTipova of the discarded exhaustive pass
             fer_launch_p_resid(d, c->st);
         }
     }
@@ -638,6 +686,32 @@ extern "C" int ferhip_encode_picture_dev(ferhip_ctx *c, int *nal_type, const uin
     if (d_rbsp) *d_rbsp = (const uint8_t *)c->d.bits;
     if (stride) *stride = c->d.bits_cap_words * 4;
     if (d_rbsp_len) *d_rbsp_len = c->d.out_bytes;
+    return 0;
+}
+
+// RBSP of the last picture -> caller buffers, asynchronously on the context's stream (so it is ordered before the
+// next picture reuses the device buffer): bytes_per_stream bytes of every stream's RBSP to dst + s * dst_stride and
+// the S lengths to len_dst.  host = 1: dst / len_dst are (pinned) host memory.  ferhip_sync() waits.
+extern "C" int ferhip_copy_rbsp(ferhip_ctx *c, void *dst, size_t dst_stride, size_t bytes_per_stream, uint32_t *len_dst, int host)
+{
+    if (!c || !dst || !len_dst) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
+    FerDev &d = c->d;
+    const size_t cap = d.bits_cap_words * 4;
+    if (bytes_per_stream > cap) bytes_per_stream = cap;
+    if (bytes_per_stream > dst_stride) return FERHIP_E_ARG;
+    const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    CK(hipMemcpy2DAsync(dst, dst_stride, d.bits, cap, bytes_per_stream, (size_t)d.S, kind, c->st));
+    CK(hipMemcpyAsync(len_dst, d.out_bytes, sizeof(uint32_t) * d.S, kind, c->st));
+    return 0;
+}
+
+extern "C" int ferhip_sync(ferhip_ctx *c)
+{
+    if (!c) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
+    CK(hipStreamSynchronize(c->st));
+    CK(hipStreamSynchronize(c->st_hi));
     return 0;
 }
 
@@ -766,13 +840,14 @@ extern "C" int ferhip_get_profile(ferhip_ctx *c, double *ms, long *launches, int
 // ---- per-stage entry points
 static void set_all_types(ferhip_ctx *c, int slice_type)
 {
+    if (hdr_begin(c)) return;
     for (int s = 0; s < c->d.S; s++) {
         c->h_hdr[s * 4 + 0] = c->h_hdr[s * 4 + 1] = 0;
         c->h_hdr[s * 4 + 2] = 1;
         c->h_hdr[s * 4 + 3] = (uint32_t)slice_type;
         c->types[s] = slice_type;
     }
-    hipMemcpyAsync(c->d.hdr, c->h_hdr, sizeof(uint32_t) * 4 * c->d.S, hipMemcpyHostToDevice, c->st);
+    (void)hdr_upload(c);
 }
 
 extern "C" int ferhip_fill_interpolated(ferhip_ctx *c)
@@ -807,6 +882,7 @@ extern "C" int ferhip_inter_encoding(ferhip_ctx *c)
         c->d.serial = c->d.serial % 0x7ffffff0 + 1;
         fer_launch_me_resolve(c->d, c->st);
     }
+    fer_launch_basic_stat(c->d, c->st);
     fer_launch_p_resid(c->d, c->st);  // partition merge + mvd share the residual wavefront of the macroblock
     CK(hipStreamSynchronize(c->st));
     CK(hipGetLastError());
@@ -901,15 +977,19 @@ struct HostBR {
 };
 
 struct DecHdr {
-    int have_sps, W, H, log2_max_frame_num, poc_type, log2_max_poc_lsb;
+    int have_sps, have_pps, W, H, log2_max_frame_num, poc_type, log2_max_poc_lsb;
     int pic_init_qp, chroma_qp_offset, deblock_ctl, constrained_intra;
     int mod_flag;
 };
 
-static void dec_parse_sps(DecHdr &h, HostBR &r)
+// seq_parameter_set_rbsp, F/headers_and_parameter_sets.cpp:398-470.  Returns 0, or FERHIP_E_UNSUP for syntax the
+// slice parser does not implement (the reference would mis-decode it silently).
+static int dec_parse_sps(DecHdr &h, HostBR &r)
 {
-    r.bits(24);
+    const unsigned profile_idc = r.bits(8);
+    r.bits(16);
     r.ue();
+    if (profile_idc >= 100) return FERHIP_E_UNSUP;  // High profiles carry chroma_format_idc ... here
     h.log2_max_frame_num = (int)r.ue() + 4;
     h.poc_type = (int)r.ue();
     h.log2_max_poc_lsb = 0;
@@ -925,18 +1005,22 @@ static void dec_parse_sps(DecHdr &h, HostBR &r)
     r.ue();
     r.bits(1);
     int wmb = (int)r.ue() + 1, hmu = (int)r.ue() + 1, fmo = (int)r.bits(1);
+    if (!fmo) return FERHIP_E_UNSUP;  // field / MBAFF coding
     h.W = wmb * 16;
-    h.H = (2 - fmo) * hmu * 16;
+    h.H = hmu * 16;
     h.have_sps = 1;
+    return 0;
 }
 
-static void dec_parse_pps(DecHdr &h, HostBR &r)
+// pic_parameter_set_rbsp, F/headers_and_parameter_sets.cpp:520-537
+static int dec_parse_pps(DecHdr &h, HostBR &r)
 {
     r.ue();
     r.ue();
-    r.bits(2);
-    r.ue();
-    r.ue();
+    if (r.bits(1)) return FERHIP_E_UNSUP;  // entropy_coding_mode_flag: CABAC
+    r.bits(1);
+    if (r.ue() > 0) return FERHIP_E_UNSUP;  // slice groups
+    if (r.ue() > 0) return FERHIP_E_UNSUP;  // num_ref_idx_l0_default_active_minus1: several reference indices
     r.ue();
     r.bits(3);
     h.pic_init_qp = r.se() + 26;
@@ -944,12 +1028,15 @@ static void dec_parse_pps(DecHdr &h, HostBR &r)
     h.chroma_qp_offset = r.se();
     h.deblock_ctl = (int)r.bits(1);
     h.constrained_intra = (int)r.bits(1);
+    h.have_pps = 1;
+    return 0;
 }
 
 // slice header -> info[4] = {rbsp bytes, first bit of slice_data, slice_type % 5, SliceQPy}; returns 0 or error
 static int dec_parse_slice_header(DecHdr &h, const uint8_t *rbsp, size_t n, int nal_type, int ref_idc, uint32_t *info,
                                   int &override_flag)
 {
+    if (!h.have_sps || !h.have_pps) return FERHIP_E_STATE;
     HostBR r{rbsp, n, 0};
     r.ue();
     int st = (int)r.ue() % 5;
@@ -1048,17 +1135,19 @@ static void split_stream(const uint8_t *s, size_t n, std::vector<NalRef> &out)
     }
 }
 
+// Window buffers of the decode twin.  ferhip_decode_streams keeps one arena per process between calls (releasing
+// tens of GB costs more than a window's reconstruction); it is tied to the HIP device it was allocated on and
+// can be dropped with ferhip_decode_release().  A streaming decoder (ferhip_dec_*) owns a small one of its own.
 struct DecArena {
     void *dev = nullptr;
     size_t bytes = 0;
+    int device = -1;
     uint8_t *d_rbsp = nullptr, *h_rbsp = nullptr;  // slices of a window: device buffer and pinned staging
     size_t rbsp_cap = 0;
     bool busy = false, cached = false;
 };
 static DecArena g_dec_arena;
 static std::mutex g_dec_arena_mu;
-static uint8_t *g_null_u8 = nullptr;
-static size_t g_null_sz = 0;
 static void dec_arena_free(DecArena *a)
 {
     if (a->dev) hipFree(a->dev);
@@ -1067,26 +1156,36 @@ static void dec_arena_free(DecArena *a)
     a->dev = nullptr;
     a->d_rbsp = a->h_rbsp = nullptr;
     a->bytes = a->rbsp_cap = 0;
+    a->device = -1;
 }
-static DecArena *dec_arena_acquire(size_t need)
+static DecArena *dec_arena_acquire(size_t need, int device, bool use_cache)
 {
-    DecArena *a;
-    {
+    DecArena *a = nullptr;
+    if (use_cache) {
         std::lock_guard<std::mutex> lk(g_dec_arena_mu);
         if (!g_dec_arena.busy) {
             a = &g_dec_arena;
             a->busy = true;
             a->cached = true;
-        } else {
-            a = new DecArena();
-            a->busy = true;
         }
     }
+    if (!a) {
+        a = new DecArena();
+        a->busy = true;
+    }
+    if (a->device != device && a->device >= 0) {  // allocated on another device: its pointers are useless here
+        int cur = device;
+        (void)hipSetDevice(a->device);
+        dec_arena_free(a);
+        (void)hipSetDevice(cur);
+    }
+    a->device = device;
     if (a->bytes < need) {
         if (a->dev) hipFree(a->dev);
         a->dev = nullptr;
         a->bytes = 0;
         if (hipMalloc(&a->dev, need) != hipSuccess) {
+            (void)hipGetLastError();
             a->dev = nullptr;
             std::lock_guard<std::mutex> lk(g_dec_arena_mu);
             if (a->cached)
@@ -1111,85 +1210,98 @@ static void dec_arena_release(DecArena *a)
     }
 }
 
-// decode() for S Annex-B streams side by side.  All streams must carry the same picture size.
-// out: host [T][S][W*H*3/2] (T = max_pictures); pictures[s] = pictures decoded of stream s.
-extern "C" int ferhip_decode_streams(const uint8_t *const *streams, const size_t *lens, int S, uint8_t *out,
-                                     int max_pictures, int *pictures, int *W_out, int *H_out)
+extern "C" int ferhip_decode_release(void)
 {
-    if (!streams || !lens || S <= 0 || !pictures) return FERHIP_E_ARG;
-    const bool verbose = getenv("FER_DEC_TIMING") != nullptr;
-    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_start = now(), t_parse = 0, t_recon = 0, t_pack = 0;
-    std::vector<std::vector<NalRef>> nals(S);
-    DecHdr h;
-    memset(&h, 0, sizeof h);
-    {  // NAL splitting is host work per stream: spread it over a few threads
-        const int nth = std::max(1, std::min(std::min(S, 16), (int)std::thread::hardware_concurrency()));
-        std::vector<std::thread> th;
-        for (int k = 0; k < nth; k++)
-            th.emplace_back([&, k]() {
-                for (int s = k; s < S; s += nth) split_stream(streams[s], lens[s], nals[s]);
-            });
-        for (auto &x : th) x.join();
+    std::lock_guard<std::mutex> lk(g_dec_arena_mu);
+    if (g_dec_arena.busy) return FERHIP_E_STATE;
+    if (g_dec_arena.device >= 0) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(g_dec_arena.device);
+        dec_arena_free(&g_dec_arena);
+        (void)hipSetDevice(cur);
     }
-    for (int s = 0; s < S; s++) {
-        for (auto &n : nals[s]) {
-            HostBR r{n.rbsp.data(), n.rbsp.size(), 0};
-            DecHdr hs = h;
-            if (n.type == 7) {
-                dec_parse_sps(hs, r);
-                if (h.have_sps && (hs.W != h.W || hs.H != h.H)) return FERHIP_E_ARG;
-                h = hs;
-            } else if (n.type == 8) {
-                dec_parse_pps(hs, r);
-                h = hs;
-            }
-        }
-    }
-    if (!h.have_sps) return FERHIP_E_ARG;
-    if (W_out) *W_out = h.W;
-    if (H_out) *H_out = h.H;
-    const double t_split = now();
+    return 0;
+}
+
+// One decoding session: S streams of one picture size, a window of up to TWmax pictures per stream parsed by one
+// launch, parameter sets and the state the reference keeps in globals (mb_qp_delta, ChromaACLevel) per stream.
+struct DecSession {
     ferhip_ctx *c = nullptr;
-    ferhip_params p = {26, 0, 16, 3, 1 << 30};
-    int rc = ctx_create(&c, h.W, h.H, S, &p, true);
-    if (rc) return rc;
-    FerDev &d = c->d;
-    const double t_create = now();
-    // the slice NALs of every stream, in order
-    std::vector<std::vector<const NalRef *>> slices(S);
-    size_t T = 0;
-    for (int s = 0; s < S; s++) {
-        for (auto &n : nals[s])
-            if (n.type == 1 || n.type == 5) slices[s].push_back(&n);
-        T = std::max(T, slices[s].size());
-        pictures[s] = 0;
+    int S = 0;
+    std::vector<DecHdr> hs;  // parameter sets of every stream (the QP of this codec lives in the PPS)
+    DecArena *ar = nullptr;
+    DecBatch B;
+    uint32_t *d_info = nullptr;
+    size_t TWmax = 0, nm = 0, fsz = 0;
+    std::vector<uint32_t> info, hdr;
+    std::vector<char> anyP, anyAny;
+    double t_pack = 0, t_parse = 0, t_recon = 0;
+};
+
+static double dec_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static void dec_session_close(DecSession &ss)
+{
+    if (ss.c) {
+        (void)hipSetDevice(ss.c->device);
+        hipStreamSynchronize(ss.c->st);
     }
-    if (max_pictures > 0) T = std::min(T, (size_t)max_pictures);
-    // Slice data is bit-serial, so the parser's parallelism is pictures: a window of TW pictures of all streams is
-    // parsed by one launch (one wavefront each), then reconstructed picture by picture.
-    const size_t nm = (size_t)S * d.nmb;
+    dec_arena_release(ss.ar);
+    ss.ar = nullptr;
+    if (ss.c) ferhip_destroy(ss.c);
+    ss.c = nullptr;
+}
+
+// T = pictures per stream the caller expects (sizes the window); use_cache = take the process-wide arena
+static int dec_session_open(DecSession &ss, int W, int H, int S, size_t T, bool use_cache)
+{
+    ferhip_params p = {26, 0, 16, 3, 1 << 30};
+    int rc = ctx_create(&ss.c, W, H, S, &p, true);
+    if (rc) return rc;
+    FerDev &d = ss.c->d;
+    ss.S = S;
+    ss.nm = (size_t)S * d.nmb;
+    ss.fsz = (size_t)W * H * 3 / 2;
+    const size_t nm = ss.nm;
     const size_t per_pic = nm * (4 + 16 + 2 + 24 + 16 + 16 + 1 + FER_LEVELS * 2 + 1 + 1);
-    size_t TWmax = std::min<size_t>(std::max<size_t>((size_t)48e9 / per_pic, 1), 256);
+    size_t budget = (size_t)48e9, freeb = 0, totalb = 0;
+    if (hipMemGetInfo(&freeb, &totalb) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_dec_arena_mu);
+        if (use_cache && !g_dec_arena.busy && g_dec_arena.device == ss.c->device) freeb += g_dec_arena.bytes;
+        budget = std::min(budget, freeb / 2);
+    }
+    size_t TWmax = std::min<size_t>(std::max<size_t>(budget / per_pic, 1), 256);
     TWmax = std::max<size_t>(std::min(TWmax, T), 1);
-    // The window's buffers are carved from one arena that is kept between calls (releasing tens of GB costs more
-    // than a window's reconstruction); a second call running at the same time gets its own.
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t sizes[16] = {TWmax * nm * 4, TWmax * nm * 16, TWmax * nm * 2, TWmax * nm * 24, TWmax * nm * 16, TWmax * nm * 16,
-                              TWmax * nm, TWmax * nm * FER_LEVELS * 2, TWmax * nm, TWmax * nm, TWmax * S * 16, TWmax * S * 16,
-                              TWmax * S * 16, TWmax * S * 256, TWmax * S * 256, TWmax * S * 24};
-    size_t need = 0;
-    for (size_t b : sizes) need += up(b) + 256;
-    DecArena *ar = dec_arena_acquire(need);
-    uint8_t *base = ar ? (uint8_t *)ar->dev : nullptr;
+    uint8_t *base = nullptr;
+    size_t sizes[16];
+    for (;;) {  // halve the window until its buffers fit
+        const size_t sz[16] = {TWmax * nm * 4, TWmax * nm * 16, TWmax * nm * 2, TWmax * nm * 24, TWmax * nm * 16, TWmax * nm * 16,
+                               TWmax * nm, TWmax * nm * FER_LEVELS * 2, TWmax * nm, TWmax * nm, TWmax * S * 16, TWmax * S * 16,
+                               TWmax * S * 16, TWmax * S * 256, TWmax * S * 256, TWmax * S * 24};
+        size_t need = 0;
+        for (int i = 0; i < 16; i++) {
+            sizes[i] = sz[i];
+            need += up(sz[i]) + 256;
+        }
+        ss.ar = dec_arena_acquire(need, ss.c->device, use_cache);
+        if (ss.ar) break;
+        if (TWmax == 1) {
+            dec_session_close(ss);
+            return FERHIP_E_HIP;
+        }
+        TWmax = (TWmax + 1) / 2;
+    }
+    ss.TWmax = TWmax;
+    base = (uint8_t *)ss.ar->dev;
     size_t off = 0;
     auto wmalloc = [&](size_t bytes) -> void * {
-        if (!base) return nullptr;
         void *v = base + off;
         off += up(bytes) + 256;
         return v;
     };
-    DecBatch B;
+    DecBatch &B = ss.B;
     B.mb_type = (int *)wmalloc(sizes[0]);
     B.mv = (short *)wmalloc(sizes[1]);
     B.cbp = (uint8_t *)wmalloc(sizes[2]);
@@ -1205,147 +1317,281 @@ extern "C" int ferhip_decode_streams(const uint8_t *const *streams, const size_t
     B.summ = (int *)wmalloc(sizes[12]);
     B.cac_in = (int16_t *)wmalloc(sizes[13]);
     B.cac_out = (int16_t *)wmalloc(sizes[14]);
-    uint32_t *d_info = (uint32_t *)wmalloc(sizes[15]);
-    uint8_t *&d_rbsp = ar ? ar->d_rbsp : g_null_u8, *&h_rbsp = ar ? ar->h_rbsp : g_null_u8;  // all slices of a window
-    size_t &d_rbsp_cap = ar ? ar->rbsp_cap : g_null_sz;
-    bool alloc_ok = base != nullptr;
-    const double t_alloc = now();
-    std::vector<uint32_t> info, hdr;
-    std::vector<char> anyP, anyAny;
-    const size_t fsz = (size_t)h.W * h.H * 3 / 2;
-    rc = alloc_ok ? 0 : FERHIP_E_HIP;
-    d.dec_constrained_intra = h.constrained_intra;
-    d.dec_chroma_qp_offset = h.chroma_qp_offset;
-    for (size_t t0 = 0; t0 < T && rc == 0; t0 += TWmax) {
-        const size_t TW = std::min(TWmax, T - t0);
-        double ta = now();
-        info.assign(TW * S * 6, 0);
-        hdr.assign(TW * S * 4, 0);
-        anyP.assign(TW, 0);
-        anyAny.assign(TW, 0);
-        // slice headers and the offsets of the slices in the window's RBSP buffer
-        size_t total = 0;
-        for (size_t t = 0; t < TW && rc == 0; t++)
-            for (int s = 0; s < S; s++) {
-                uint32_t *in = &info[(t * S + s) * 6];
-                hdr[(t * S + s) * 4 + 3] = 2;
-                if (t0 + t >= slices[s].size()) continue;
-                const NalRef &n = *slices[s][t0 + t];
-                int ov = 0;
-                rc = dec_parse_slice_header(h, n.rbsp.data(), n.rbsp.size(), n.type, n.ref_idc, in, ov);
-                if (rc) break;
-                in[4] = (uint32_t)total;
-                in[5] = (uint32_t)(total >> 32);
-                total += (n.rbsp.size() + 15) & ~(size_t)15;
-                hdr[(t * S + s) * 4 + 3] = in[2];
-                anyP[t] |= in[2] == 0;
-                anyAny[t] = 1;
-            }
-        if (rc) break;
-        if (total + 64 > d_rbsp_cap) {
-            if (d_rbsp) hipFree(d_rbsp);
-            if (h_rbsp) hipHostFree(h_rbsp);
-            d_rbsp = h_rbsp = nullptr;
-            d_rbsp_cap = total + total / 4 + 4096;
-            if (hipMalloc((void **)&d_rbsp, d_rbsp_cap) != hipSuccess || hipHostMalloc((void **)&h_rbsp, d_rbsp_cap) != hipSuccess) {
-                rc = FERHIP_E_HIP;
-                break;
-            }
+    ss.d_info = (uint32_t *)wmalloc(sizes[15]);
+    ss.hs.assign(S, DecHdr{});
+    return 0;
+}
+
+// Decode pictures [t0, t0 + TW) of every stream: slices[s][t] = the slice NAL of picture t of stream s (streams may
+// be shorter).  out (host, may be NULL) receives picture t of stream s at (t * S + s) * fsz; pictures[s] counts.
+static int dec_session_window(DecSession &ss, const std::vector<std::vector<const NalRef *>> &slices, size_t t0, size_t TW,
+                              uint8_t *out, int *pictures)
+{
+    ferhip_ctx *c = ss.c;
+    FerDev &d = c->d;
+    const int S = ss.S;
+    const size_t nm = ss.nm;
+    DecBatch &B = ss.B;
+    DecArena *ar = ss.ar;
+    double ta = dec_now();
+    ss.info.assign(TW * S * 6, 0);
+    ss.hdr.assign(TW * S * 4, 0);
+    ss.anyP.assign(TW, 0);
+    ss.anyAny.assign(TW, 0);
+    // slice headers and the offsets of the slices in the window's RBSP buffer
+    size_t total = 0;
+    for (size_t t = 0; t < TW; t++)
+        for (int s = 0; s < S; s++) {
+            uint32_t *in = &ss.info[(t * S + s) * 6];
+            uint32_t *hd = &ss.hdr[(t * S + s) * 4];
+            hd[3] = 2;
+            if (t0 + t >= slices[s].size()) continue;
+            const NalRef &n = *slices[s][t0 + t];
+            int ov = 0;
+            int rc = dec_parse_slice_header(ss.hs[s], n.rbsp.data(), n.rbsp.size(), n.type, n.ref_idc, in, ov);
+            if (rc) return rc;
+            in[4] = (uint32_t)total;
+            in[5] = (uint32_t)(total >> 32);
+            total += (n.rbsp.size() + 15) & ~(size_t)15;
+            // what the kernels need of this stream's PPS travels with the picture
+            hd[0] = (uint32_t)ss.hs[s].chroma_qp_offset;
+            hd[1] = (uint32_t)ss.hs[s].constrained_intra;
+            hd[3] = in[2];
+            ss.anyP[t] |= in[2] == 0;
+            ss.anyAny[t] = 1;
         }
-        {  // gather the slices into the pinned staging buffer with a few threads, then one H2D copy
-            const int nth = std::max(1, std::min(std::min(S, 16), (int)std::thread::hardware_concurrency()));
+    if (total + 64 > ar->rbsp_cap) {
+        if (ar->d_rbsp) hipFree(ar->d_rbsp);
+        if (ar->h_rbsp) hipHostFree(ar->h_rbsp);
+        ar->d_rbsp = ar->h_rbsp = nullptr;
+        ar->rbsp_cap = total + total / 4 + 4096;
+        if (hipMalloc((void **)&ar->d_rbsp, ar->rbsp_cap) != hipSuccess || hipHostMalloc((void **)&ar->h_rbsp, ar->rbsp_cap) != hipSuccess) {
+            ar->rbsp_cap = 0;
+            return FERHIP_E_HIP;
+        }
+    }
+    {  // gather the slices into the pinned staging buffer with a few threads, then one H2D copy
+        const int nth = std::max(1, std::min(std::min(S, 16), (int)std::thread::hardware_concurrency()));
+        auto gather = [&](int k) {
+            for (int s = k; s < S; s += nth)
+                for (size_t t = 0; t < TW; t++) {
+                    if (t0 + t >= slices[s].size()) continue;
+                    const NalRef &n = *slices[s][t0 + t];
+                    const uint32_t *in = &ss.info[(t * S + s) * 6];
+                    memcpy(ar->h_rbsp + (((size_t)in[5] << 32) | in[4]), n.rbsp.data(), n.rbsp.size());
+                }
+        };
+        if (nth == 1) {
+            gather(0);
+        } else {
             std::vector<std::thread> th;
-            for (int k = 0; k < nth; k++)
-                th.emplace_back([&, k]() {
-                    for (int s = k; s < S; s += nth)
-                        for (size_t t = 0; t < TW; t++) {
-                            if (t0 + t >= slices[s].size()) continue;
-                            const NalRef &n = *slices[s][t0 + t];
-                            const uint32_t *in = &info[(t * S + s) * 6];
-                            memcpy(h_rbsp + (((size_t)in[5] << 32) | in[4]), n.rbsp.data(), n.rbsp.size());
-                        }
-                });
+            for (int k = 0; k < nth; k++) th.emplace_back(gather, k);
             for (auto &x : th) x.join();
         }
-        if (hipMemcpyAsync(d_rbsp, h_rbsp, total, hipMemcpyHostToDevice, c->st) != hipSuccess ||
-            hipMemcpyAsync(d_info, info.data(), info.size() * 4, hipMemcpyHostToDevice, c->st) != hipSuccess ||
-            hipMemcpyAsync(B.hdr, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice, c->st) != hipSuccess) {
-            rc = FERHIP_E_HIP;
-            break;
+    }
+    if (hipMemcpyAsync(ar->d_rbsp, ar->h_rbsp, total, hipMemcpyHostToDevice, c->st) != hipSuccess ||
+        hipMemcpyAsync(ss.d_info, ss.info.data(), ss.info.size() * 4, hipMemcpyHostToDevice, c->st) != hipSuccess ||
+        hipMemcpyAsync(B.hdr, ss.hdr.data(), ss.hdr.size() * 4, hipMemcpyHostToDevice, c->st) != hipSuccess)
+        return FERHIP_E_HIP;
+    B.TW = (int)TW;
+    B.rbsp = ar->d_rbsp;
+    B.info = ss.d_info;
+    ss.t_pack += dec_now() - ta;
+    ta = dec_now();
+    fer_launch_decode_parse(d, B, c->st);
+    // the host vectors above are read by the copies when they execute: the synchronisation below covers them
+    if (hipMemcpyAsync(c->h_status, d.status, sizeof(int) * S, hipMemcpyDeviceToHost, c->st) != hipSuccess ||
+        hipStreamSynchronize(c->st) != hipSuccess || hipGetLastError() != hipSuccess)
+        return FERHIP_E_HIP;
+    for (int s = 0; s < S; s++)
+        if (c->h_status[s]) {
+            fprintf(stderr, "ferhip: stream %d decode status 0x%x\n", s, c->h_status[s]);
+            return (c->h_status[s] & FER_ERR_DEC_UNSUPPORTED) ? FERHIP_E_UNSUP : FERHIP_E_DEVICE;
         }
-        B.TW = (int)TW;
-        B.rbsp = d_rbsp;
-        B.info = d_info;
-        t_pack += now() - ta;
-        ta = now();
-        fer_launch_decode_parse(d, B, c->st);
-        if (hipMemcpyAsync(c->h_status, d.status, sizeof(int) * S, hipMemcpyDeviceToHost, c->st) != hipSuccess ||
-            hipStreamSynchronize(c->st) != hipSuccess || hipGetLastError() != hipSuccess) {
-            rc = FERHIP_E_HIP;
-            break;
+    ss.t_parse += dec_now() - ta;
+    ta = dec_now();
+    for (size_t t = 0; t < TW; t++) {
+        if (!ss.anyAny[t]) break;
+        // `frame` keeps the previous picture where the parser does not reach (F/rbsp_decoding.cpp:77)
+        if (hipMemcpyAsync(c->planes[c->cur_set], c->planes[c->cur_set ^ 1], d.ysz * 3 / 2 * S, hipMemcpyDeviceToDevice, c->st) !=
+            hipSuccess)
+            return FERHIP_E_HIP;
+        FerDev ds = d;  // this picture's slice of the window
+        const size_t o = t * nm;
+        ds.mb_type = B.mb_type + o;
+        ds.mv = B.mv + o * 8;
+        ds.cbp = B.cbp + o * 2;
+        ds.tc = B.tc + o * 24;
+        ds.i4mode = B.i4mode + o * 16;
+        ds.i4flag = B.i4flag + o * 16;
+        ds.chroma_mode = B.chroma_mode + o;
+        ds.levels = B.levels + o * FER_LEVELS;
+        ds.dec_qp = B.dec_qp + o;
+        ds.hdr = B.hdr + t * S * 4;
+        ds.dec_state = B.state + t * S * 4;
+        fer_launch_decode_recon(ds, ss.anyP[t] != 0, true, c->st);
+        c->cur_set ^= 1;  // the decoded picture becomes the reference (modificationProcess -> frameDeepCopy)
+        bind_planes(c);
+        if (out) {
+            int rc = ferhip_get_recon(c, out + (t0 + t) * S * ss.fsz, 1);
+            if (rc) return rc;
         }
-        for (int s = 0; s < S && rc == 0; s++)
-            if (c->h_status[s]) {
-                fprintf(stderr, "ferhip: stream %d decode status 0x%x\n", s, c->h_status[s]);
-                rc = (c->h_status[s] & FER_ERR_DEC_UNSUPPORTED) ? FERHIP_E_UNSUP : FERHIP_E_DEVICE;
-            }
-        t_parse += now() - ta;
-        ta = now();
-        for (size_t t = 0; t < TW && rc == 0; t++) {
-            if (!anyAny[t]) break;
-            // `frame` keeps the previous picture where the parser does not reach (F/rbsp_decoding.cpp:77)
-            if (hipMemcpyAsync(c->planes[c->cur_set], c->planes[c->cur_set ^ 1], d.ysz * 3 / 2 * S, hipMemcpyDeviceToDevice,
-                               c->st) != hipSuccess) {
-                rc = FERHIP_E_HIP;
-                break;
-            }
-            FerDev ds = d;  // this picture's slice of the window
-            const size_t o = t * nm;
-            ds.mb_type = B.mb_type + o;
-            ds.mv = B.mv + o * 8;
-            ds.cbp = B.cbp + o * 2;
-            ds.tc = B.tc + o * 24;
-            ds.i4mode = B.i4mode + o * 16;
-            ds.i4flag = B.i4flag + o * 16;
-            ds.chroma_mode = B.chroma_mode + o;
-            ds.levels = B.levels + o * FER_LEVELS;
-            ds.dec_qp = B.dec_qp + o;
-            ds.hdr = B.hdr + t * S * 4;
-            ds.dec_state = B.state + t * S * 4;
-            fer_launch_decode_recon(ds, anyP[t] != 0, true, c->st);
-            c->cur_set ^= 1;  // the decoded picture becomes the reference (modificationProcess -> frameDeepCopy)
-            bind_planes(c);
-            if (out) {
-                rc = ferhip_get_recon(c, out + (t0 + t) * S * fsz, 1);
-                if (rc) break;
-            }
+        if (pictures)
             for (int s = 0; s < S; s++)
                 if (t0 + t < slices[s].size()) pictures[s]++;
-        }
-        if (rc == 0 && (hipStreamSynchronize(c->st) != hipSuccess || hipGetLastError() != hipSuccess)) rc = FERHIP_E_HIP;
-        t_recon += now() - ta;
     }
+    if (hipStreamSynchronize(c->st) != hipSuccess || hipGetLastError() != hipSuccess) return FERHIP_E_HIP;
+    ss.t_recon += dec_now() - ta;
+    return 0;
+}
+
+// decode() for S Annex-B streams side by side.  All streams must carry the same picture size.
+// out: host [T][S][W*H*3/2] (T = max_pictures); pictures[s] = pictures decoded of stream s.
+extern "C" int ferhip_decode_streams(const uint8_t *const *streams, const size_t *lens, int S, uint8_t *out,
+                                     int max_pictures, int *pictures, int *W_out, int *H_out)
+{
+    if (!streams || !lens || S <= 0 || !pictures) return FERHIP_E_ARG;
+    if (out && max_pictures <= 0) return FERHIP_E_ARG;  // `out` holds max_pictures pictures per stream: its size must be known
+    const bool verbose = getenv("FER_DEC_TIMING") != nullptr;
+    double t_start = dec_now();
+    std::vector<std::vector<NalRef>> nals(S);
+    {  // NAL splitting is host work per stream: spread it over a few threads
+        const int nth = std::max(1, std::min(std::min(S, 16), (int)std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (int k = 0; k < nth; k++)
+            th.emplace_back([&, k]() {
+                for (int s = k; s < S; s += nth) split_stream(streams[s], lens[s], nals[s]);
+            });
+        for (auto &x : th) x.join();
+    }
+    // parameter sets per stream (the last SPS / PPS of a stream wins, as in the reference, which keeps one of each)
+    std::vector<DecHdr> hs(S, DecHdr{});
+    for (int s = 0; s < S; s++) {
+        for (auto &n : nals[s]) {
+            HostBR r{n.rbsp.data(), n.rbsp.size(), 0};
+            int rc = 0;
+            if (n.type == 7)
+                rc = dec_parse_sps(hs[s], r);
+            else if (n.type == 8)
+                rc = dec_parse_pps(hs[s], r);
+            if (rc) return rc;
+        }
+        if (!hs[s].have_sps || !hs[s].have_pps) return FERHIP_E_ARG;
+        if (hs[s].W != hs[0].W || hs[s].H != hs[0].H) return FERHIP_E_ARG;
+    }
+    if (W_out) *W_out = hs[0].W;
+    if (H_out) *H_out = hs[0].H;
+    const double t_split = dec_now();
+    // the slice NALs of every stream, in order
+    std::vector<std::vector<const NalRef *>> slices(S);
+    size_t T = 0;
+    for (int s = 0; s < S; s++) {
+        for (auto &n : nals[s])
+            if (n.type == 1 || n.type == 5) slices[s].push_back(&n);
+        T = std::max(T, slices[s].size());
+        pictures[s] = 0;
+    }
+    if (max_pictures > 0) T = std::min(T, (size_t)max_pictures);
+    for (int s = 0; s < S; s++)
+        if (slices[s].size() > T) slices[s].resize(T);
+    DecSession ss;
+    int rc = dec_session_open(ss, hs[0].W, hs[0].H, S, T, true);
+    if (rc) return rc;
+    ss.hs = hs;
+    const double t_open = dec_now();
+    // Slice data is bit-serial, so the parser's parallelism is pictures: a window of TW pictures of all streams is
+    // parsed by one launch (one wavefront each), then reconstructed picture by picture.
+    for (size_t t0 = 0; t0 < T && rc == 0; t0 += ss.TWmax) rc = dec_session_window(ss, slices, t0, std::min(ss.TWmax, T - t0), out, pictures);
     if (verbose)
-        fprintf(stderr, "ferhip_decode_streams: %d streams, %zu pictures, window %zu: split %.3f s, context %.3f s, buffers %.3f s, "
-                        "pack+H2D %.3f s, parse %.3f s, reconstruction %.3f s\n", S, T, TWmax, t_split - t_start, t_create - t_split,
-                t_alloc - t_create, t_pack, t_parse, t_recon);
-    for (int s = 0; s < S; s++) c->ss[s].have_dpb = 1;
+        fprintf(stderr, "ferhip_decode_streams: %d streams, %zu pictures, window %zu: split %.3f s, context + buffers %.3f s, "
+                        "pack+H2D %.3f s, parse %.3f s, reconstruction %.3f s\n", S, T, ss.TWmax, t_split - t_start, t_open - t_split,
+                ss.t_pack, ss.t_parse, ss.t_recon);
 #ifdef FER_PROBE
     {
         long long tm[64];
         hipDeviceSynchronize();
-        hipMemcpy(tm, c->d.timing, sizeof tm, hipMemcpyDeviceToHost);
+        hipMemcpy(tm, ss.c->d.timing, sizeof tm, hipMemcpyDeviceToHost);
         double n = tm[52] > 0 ? (double)tm[52] : 1.0;
         fprintf(stderr, "k_dec_parse stream 0: %lld MBs, us per MB: header %.2f residual %.2f tail %.2f skip/loop %.2f\n", tm[52],
                 tm[48] / n / 100, tm[49] / n / 100, tm[50] / n / 100, tm[51] / n / 100);
     }
 #endif
-    hipStreamSynchronize(c->st);
-    const double t_free0 = now();
-    dec_arena_release(ar);
-    ferhip_destroy(c);
-    if (verbose) fprintf(stderr, "ferhip_decode_streams: release %.3f s, total %.3f s\n", now() - t_free0, now() - t_start);
+    const double t_free0 = dec_now();
+    dec_session_close(ss);
+    if (verbose) fprintf(stderr, "ferhip_decode_streams: release %.3f s, total %.3f s\n", dec_now() - t_free0, dec_now() - t_start);
     return rc;
+}
+
+// ---- streaming decoder: RBSP_decode(NALunit) of F/rbsp_decoding.cpp:17 for one stream, NAL unit by NAL unit ----
+struct ferhip_dec {
+    DecSession ss;
+    DecHdr h{};
+    bool open = false;
+    int pictures = 0;
+};
+
+extern "C" int ferhip_dec_create(ferhip_dec **out)
+{
+    if (!out) return FERHIP_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        fprintf(stderr, "ferhip: no HIP device; the hot path has no CPU fallback\n");
+        return FERHIP_E_HIP;
+    }
+    *out = new ferhip_dec();
+    return 0;
+}
+
+extern "C" void ferhip_dec_destroy(ferhip_dec *dc)
+{
+    if (!dc) return;
+    if (dc->open) dec_session_close(dc->ss);
+    delete dc;
+}
+
+extern "C" int ferhip_dec_nal(ferhip_dec *dc, int nal_unit_type, int nal_ref_idc, const uint8_t *rbsp, size_t n, uint8_t *picture,
+                              int *got_picture, int *width, int *height)
+{
+    if (!dc || !rbsp || n == 0) return FERHIP_E_ARG;
+    if (got_picture) *got_picture = 0;
+    HostBR r{rbsp, n, 0};
+    if (nal_unit_type == 7) {  // fill_sps + init_h264_structures + AllocateMemory
+        DecHdr hn = dc->h;
+        int rc = dec_parse_sps(hn, r);
+        if (rc) return rc;
+        if (dc->open && (hn.W != dc->h.W || hn.H != dc->h.H)) {
+            dec_session_close(dc->ss);
+            dc->open = false;
+        }
+        dc->h = hn;
+        if (!dc->open) {
+            dc->ss = DecSession();
+            rc = dec_session_open(dc->ss, hn.W, hn.H, 1, 1, false);
+            if (rc) return rc;
+            dc->open = true;
+        }
+    } else if (nal_unit_type == 8) {
+        int rc = dec_parse_pps(dc->h, r);
+        if (rc) return rc;
+    } else if (nal_unit_type == 5 || nal_unit_type == 1) {
+        if (!dc->open) return FERHIP_E_STATE;
+        (void)hipSetDevice(dc->ss.c->device);
+        dc->ss.hs[0] = dc->h;
+        NalRef nal;
+        nal.type = nal_unit_type;
+        nal.ref_idc = nal_ref_idc;
+        nal.rbsp.assign(rbsp, rbsp + n);
+        std::vector<std::vector<const NalRef *>> slices(1);
+        slices[0].push_back(&nal);
+        int rc = dec_session_window(dc->ss, slices, 0, 1, picture, nullptr);
+        if (rc) return rc;
+        dc->h.mod_flag = dc->ss.hs[0].mod_flag;
+        dc->pictures++;
+        if (got_picture) *got_picture = 1;
+    }  // every other NAL unit type (SEI, AUD ...) is ignored, as in the reference
+    if (width) *width = dc->h.W;
+    if (height) *height = dc->h.H;
+    return 0;
 }
 
 // ---- block-level KATs: forwardResidual / inverseResidual on the device

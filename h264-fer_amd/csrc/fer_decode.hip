@@ -470,6 +470,7 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
         }
         return;
     }
+    const bool constrained_intra = __builtin_amdgcn_readfirstlane((int)B.hdr[pic * 4 + 1]) != 0;
     DecBits b;
     db_open(b, B.rbsp + (((size_t)i_hi << 32) | i_lo), i_size, i_pos);
     int QPy = __builtin_amdgcn_readfirstlane((int)info[3]);
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
         const bool i4 = stype == 2 ? t == 0 : t == 5;
         const bool i16 = stype == 2 ? (t >= 1 && t <= 24) : (t >= 6 && t <= 29);
         const bool inter = !i4 && !i16;
-        if (t == 25 && stype == 2) {
+        if ((t == 25 && stype == 2) || (t == 30 && stype != 2)) {
             atomicOr(&d.status[s], FER_ERR_DEC_UNSUPPORTED);  // I_PCM
             break;
         }
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
                 bool edgeB = blk == 0 || blk == 1 || blk == 4 || blk == 5;
                 bool okA = !(edgeA && cur % d.mbw == 0), okB = !(edgeB && cur < d.mbw);
                 int mA = 2, mB = 2;
-                if (okA && okB && !d.dec_constrained_intra) {
+                if (okA && okB && !constrained_intra) {
                     int ma = edgeA ? cur - 1 : cur, mb2 = edgeB ? cur - d.mbw : cur;
                     int ta = mbt[ma], tb = mbt[mb2];
                     bool a4 = stype == 2 ? ta == 0 : ta == 5, b4 = stype == 2 ? tb == 0 : tb == 5;
@@ -752,12 +753,14 @@ __device__ __forceinline__ void recon_block(const int16_t *__restrict__ lvl, int
     for (int i = 0; i < 16; i++) dst[(size_t)(i >> 2) * stride + (i & 3)] = (uint8_t)clip255(p[i] + r[i]);
 }
 
-__device__ __forceinline__ int dec_qpc(const FerDev &d, int QPy)
+// chroma_qp_index_offset and constrained_intra_pred_flag belong to the stream's PPS: they travel with the picture in
+// hdr[s][0] and hdr[s][1] (hdr[s][3] = slice type)
+__device__ __forceinline__ int dec_qpc(const FerDev &d, int s, int QPy)
 {
     const int qpc[52] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
                          18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33,
                          34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
-    return qpc[iclamp(QPy + d.dec_chroma_qp_offset, 0, 51)];
+    return qpc[iclamp(QPy + (int)d.hdr[s * 4], 0, 51)];
 }
 
 // chroma residual of lanes 16..23 (dc Hadamard shared through shuffles), F/inttransform.cpp:237-320
@@ -827,7 +830,7 @@ __global__ __launch_bounds__(64) void k_dec_inter(FerDev d)
         for (int i = 0; i < 16; i++) p[i] = pL[y0 + (i >> 2)][x0 + (i & 3)];
         recon_block(lv + lane * 16, 16, 0, false, QPy, p, Y + (size_t)(yp + y0) * W + xp + x0, W);
     }
-    recon_chroma(d, lv, lane, dec_qpc(d, QPy), pC, C0, C1, Wc, xp, yp);
+    recon_chroma(d, lv, lane, dec_qpc(d, s, QPy), pC, C0, C1, Wc, xp, yp);
 }
 
 __global__ __launch_bounds__(64) void k_dec_intra(FerDev d, int diag)
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(64) void k_dec_intra(FerDev d, int diag)
         }
     }
     __syncthreads();
-    recon_chroma(d, lv, lane, dec_qpc(d, QPy), &L.predC[0][0][0], Cp[0], Cp[1], Wc, xp, yp);
+    recon_chroma(d, lv, lane, dec_qpc(d, s, QPy), &L.predC[0][0][0], Cp[0], Cp[1], Wc, xp, yp);
 }
 
 void fer_launch_decode_parse(const FerDev &d, const DecBatch &B, hipStream_t st)

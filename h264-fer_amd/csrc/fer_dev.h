@@ -78,7 +78,6 @@ struct FerDev {
     int *dec_state;      // [S][4]: [0] mb_qp_delta carried from picture to picture; the reconstruction kernels are given the
                          // per-picture state here ([1] = macroblocks the parser reached)
     int16_t *dec_cac;    // [S][2][4][16] persistent ChromaACLevel
-    int dec_constrained_intra, dec_chroma_qp_offset;
 };
 
 // One window of pictures of the decode twin: slice data of TW pictures x S streams is parsed in one launch, so the

@@ -22,6 +22,8 @@ int vrijeme = 0;
 
 static ferhip_ctx *g_ctx = nullptr;
 static int g_have_dpb = 0;
+static ferhip_dec *g_dec = nullptr;
+extern "C" void ferhip_legacy_frame_alloc(void);
 
 static int ensure_ctx()
 {
@@ -39,6 +41,7 @@ extern "C" void RBSP_encode(NALunit *nu)
     if (ensure_ctx()) return;
     if (nu->nal_unit_type == 7) {
         nu->NumBytesInRBSP = (unsigned)ferhip_write_sps(g_ctx, nu->rbsp_byte, 500000);
+        ferhip_legacy_frame_alloc();  // init_h264_structures_encoder(): `frame` exists from the SPS on
         return;
     }
     if (nu->nal_unit_type == 8) {
@@ -89,4 +92,48 @@ extern "C" int selectNALUnitType(void)
     int type = 5;
     if (ferhip_set_frames(g_ctx, pic.data(), 1) || ferhip_select_nal_type(g_ctx, &type)) return 5;
     return type;
+}
+
+// RBSP_decode(NALunit nal_unit), F/rbsp_decoding.h:3, F/rbsp_decoding.cpp:17-367, the callee of decode()'s
+// getNAL loop (F/fer_h264.cpp:37-47): nal_unit_type 7 / 8 take the parameter sets (the SPS sizes and allocates
+// `frame`), 5 / 1 decode one picture into `frame`, which becomes the reference picture, and append it to
+// `yuvoutput` with writeToY4M() when that file is open (F/rbsp_decoding.cpp:364); other types are ignored.
+// The macroblock loop runs on the GPU (ferhip_dec_nal); there is no CPU fallback.
+extern "C" void RBSP_decode(NALunit nal_unit)
+{
+    if (!nal_unit.rbsp_byte || nal_unit.NumBytesInRBSP == 0) return;
+    if (!g_dec && ferhip_dec_create(&g_dec)) {
+        fprintf(stderr, "RBSP_decode: no GPU decoder (there is no CPU fallback)\n");
+        return;
+    }
+    const int type = (int)nal_unit.nal_unit_type;
+    int got = 0, W = 0, H = 0;
+    std::vector<unsigned char> pic;
+    if (type == 5 || type == 1) pic.resize((size_t)frame.Lwidth * frame.Lheight * 3 / 2);
+    int rc = ferhip_dec_nal(g_dec, type, (int)nal_unit.nal_ref_idc, nal_unit.rbsp_byte, nal_unit.NumBytesInRBSP,
+                            pic.empty() ? nullptr : pic.data(), &got, &W, &H);
+    if (rc) {
+        fprintf(stderr, "RBSP_decode: NAL unit type %d failed (%d)\n", type, rc);
+        return;
+    }
+    if (type == 7) {  // fill_sps + init_h264_structures: `frame` takes the picture size
+        if (frame.L && (frame.Lwidth != W || frame.Lheight != H)) {
+            delete[] frame.L;
+            delete[] frame.C[0];
+            delete[] frame.C[1];
+            frame.L = frame.C[0] = frame.C[1] = nullptr;
+        }
+        frame.Lwidth = W;
+        frame.Lheight = H;
+        frame.Cwidth = W >> 1;
+        frame.Cheight = H >> 1;
+        ferhip_legacy_frame_alloc();
+    }
+    if (got) {
+        size_t ys = (size_t)W * H, cs = ys / 4;
+        memcpy(frame.L, pic.data(), ys);
+        memcpy(frame.C[0], pic.data() + ys, cs);
+        memcpy(frame.C[1], pic.data() + ys + cs, cs);
+        writeToY4M();
+    }
 }

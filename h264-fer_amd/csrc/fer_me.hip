@@ -388,6 +388,10 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     su[3] = wave_sum((py & 3) > 1 ? 0 : v);
     su[4] = wave_sum((px & 3) > 1 ? 0 : v);
     if (lane < 5) d.suma[pidx * 5 + lane] = su[lane];
+    if (d.basic) {  // BasicInterEncoding: stages 2 and 3 are not run (F/moestimation.cpp:470), only the sums are needed
+        if (lane == 0) d.st3n[pidx] = 0;
+        return;
+    }
     const SuPk sp = su_pack(su);
     PP_MARK(0)
 
@@ -805,7 +809,7 @@ __device__ __forceinline__ void res_prefetch(const FerDev &d, int s, int gx, int
     p.c3x = p.c3y = p.c3s = 0;
 #pragma unroll
     for (int u = 0; u < FER_ST2_CAP / 64; u++) p.e2[u] = make_int2(0, 0);
-    if (role == 1) {
+    if (role == 1 && !d.basic) {
         p.n2raw = d.st2n[pidx];
         p.n2 = min(p.n2raw, FER_ST2_CAP);
         p.n3 = (d.dbg & 64) ? 0 : d.st3n[pidx];
@@ -1185,7 +1189,8 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
                 unsigned long long w = (unsigned)r | ((unsigned long long)(serial | (sk ? CH_SKIP : 0u)) << 32);
                 if (part == 0 && ln == 0) {
                     mbt[mb] = sk ? FER_P_SKIP : FER_P_8x8ref0;  // also clears a P_Skip left by the previous picture
-                    if (sk) atomicAdd(&d.stats[s * 5 + 0], 1);
+                    // BasicInterEncoding makes the P_Skip test twice and counts it twice (F/moestimation.cpp:324,421)
+                    if (sk) atomicAdd(&d.stats[s * 5 + 0], d.basic ? 2 : 1);
                 }
                 const int nq = sk ? 4 : 1, q0 = sk ? 0 : part;
                 if (ln < nq) {
@@ -1225,6 +1230,56 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
     }
 }
 
+// ------------------------------------------------------------------ k_basic_stat
+// BasicInterEncoding == true: interEncoding first runs basicInterEncoding (F/moestimation.cpp:298-390), whose
+// vectors it then discards (:394-397); what survives of that pass is brojTipova.  Its exhaustive loop scores
+// partition i with sadLuma8x8(predL, i), which reads the TOP-LEFT 8x8 of predL for every i (:197-212), and moves
+// only sub-block 0 of the partition (mvL0x[CurrMbAddr][i][0]); so for i = 0 the SAD varies with the candidate
+// through the first 4x4 block alone, and for i = 1..3 it is constant and the first candidate (-W/2, -W/2) stays.
+// The macroblock therefore counts as 16x16 when no later candidate of partition 0 beats the first one, as
+// 8x8 otherwise (the 16x8 / 8x16 tests cannot hold unless all four agree).  One wavefront per macroblock,
+// run between k_me_resolve (P_Skip known) and k_p_resid (which overwrites the source).
+__global__ __launch_bounds__(64) void k_basic_stat(FerDev d)
+{
+    const int lane = threadIdx.x;
+    const int s = blockIdx.y, mb = blockIdx.x;
+    if (d.hdr[s * 4 + 3] != 0) return;
+    if (d.mb_type[(size_t)s * d.nmb + mb] == FER_P_SKIP) return;
+    const int W = d.W, H = d.H;
+    const uint8_t *Y = d.curY + (size_t)s * d.ysz;
+    const uint8_t *RY = d.refY + (size_t)s * d.ysz;
+    const uint8_t *Ps = d.interp + (size_t)s * 16 * d.ysz;
+    const int xp = (mb % d.mbw) << 4, yp = (mb / d.mbw) << 4;
+    int src[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        uint32_t v = *(const uint32_t *)(Y + (size_t)(yp + y) * W + xp);
+#pragma unroll
+        for (int k = 0; k < 4; k++) src[y][k] = (v >> (8 * k)) & 0xff;
+    }
+    const int R = d.window / 2, n = 2 * R + 1;
+    int best = 0x7fffffff;  // sad << 13 | arrival index (n * n <= 4225 at WindowSize 64)
+    for (int c = lane; c < n * n; c += 64) {
+        const int mvx = c / n - R, mvy = c % n - R;  // quarter-pel units, tmvx outer, tmvy inner
+        int sad = 0;
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            int p[4];
+            mc_luma4(RY, Ps, d.ysz, W, H, xp, yp, 0, y, mvx, mvy, p);
+#pragma unroll
+            for (int k = 0; k < 4; k++) sad += iabs(src[y][k] - p[k]);
+        }
+        best = min(best, (sad << 13) | c);
+    }
+    const int w = wave_min(best);
+    if (lane == 0) atomicAdd(&d.stats[s * 5 + ((w & 0x1fff) == 0 ? 1 : 4)], 1);
+}
+
+void fer_launch_basic_stat(const FerDev &d, hipStream_t st)
+{
+    if (d.basic) hipLaunchKernelGGL(k_basic_stat, dim3(d.nmb, d.S), dim3(64), 0, st, d);
+}
+
 void fer_launch_me_pre(const FerDev &d, hipStream_t st)
 {
     dim3 g(d.nmb * 4, d.S);
@@ -1238,6 +1293,7 @@ void fer_launch_me_pre(const FerDev &d, hipStream_t st)
 
 void fer_launch_me_walk(const FerDev &d, hipStream_t st)
 {
+    if (d.basic) return;  // stage 2 is not run (F/moestimation.cpp:470)
     hipLaunchKernelGGL(k_me_walk, dim3(d.nmb * 4, d.S), dim3(64), 0, st, d);
 }
 

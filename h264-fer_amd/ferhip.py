@@ -48,6 +48,8 @@ def load_library():
     lib.ferhip_encode_picture.argtypes = [vp, C.POINTER(i), vp, sz, C.POINTER(C.c_uint32)]
     lib.ferhip_encode_picture_dev.argtypes = [vp, C.POINTER(i), C.POINTER(vp), C.POINTER(sz), C.POINTER(vp)]
     lib.ferhip_select_nal_type.argtypes = [vp, C.POINTER(i)]
+    lib.ferhip_copy_rbsp.argtypes = [vp, vp, sz, sz, vp, i]
+    lib.ferhip_sync.argtypes = [vp]
     lib.ferhip_get_recon.argtypes = [vp, vp, i]
     lib.ferhip_write_sps.argtypes = [vp, vp, sz]
     lib.ferhip_write_sps.restype = sz
@@ -65,6 +67,17 @@ def load_library():
     lib.ferhip_profile.argtypes = [vp, i]
     lib.ferhip_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), i]
     lib.ferhip_decode_streams.argtypes = [C.POINTER(C.c_char_p), C.POINTER(sz), i, vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    lib.ferhip_decode_release.argtypes = []
+    lib.ferhip_dec_create.argtypes = [C.POINTER(vp)]
+    lib.ferhip_dec_destroy.argtypes = [vp]
+    lib.ferhip_dec_destroy.restype = None
+    lib.ferhip_dec_nal.argtypes = [vp, i, i, vp, sz, vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    lib.ferhip_y4m_open.argtypes = [C.POINTER(vp), C.c_char_p, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    lib.ferhip_y4m_read.argtypes = [vp, vp]
+    lib.ferhip_y4m_close.argtypes = [vp]
+    lib.ferhip_y4m_close.restype = None
+    lib.ferhip_y4m_write_header.argtypes = [vp, i, i]
+    lib.ferhip_y4m_write_frame.argtypes = [vp, vp, i, i, i]
     lib.ferhip_forward_residual.argtypes = [i, vp, vp, i, sz]
     lib.ferhip_inverse_residual.argtypes = [i, vp, vp, i, sz]
     _lib = lib
@@ -129,6 +142,22 @@ class FerHip:
         _chk(self.lib.ferhip_encode_picture_dev(self.ctx, nt, C.byref(p), C.byref(st), C.byref(pl)),
              "ferhip_encode_picture_dev")
         return p.value, st.value, pl.value, list(nt)
+
+    def copy_rbsp_device(self, dst_ptr, len_ptr, stride=None, nbytes=None):
+        """RBSP + lengths of the last picture -> device buffers, on the library's stream (asynchronous)."""
+        stride = stride or (self.nmb * 1024 + 4096)
+        _chk(self.lib.ferhip_copy_rbsp(self.ctx, C.c_void_p(int(dst_ptr)), stride, nbytes or stride, C.c_void_p(int(len_ptr)), 0),
+             "ferhip_copy_rbsp")
+
+    def copy_rbsp_host(self, dst, lens, nbytes):
+        """... -> host arrays dst [S][stride] uint8 (pinned for asynchrony), lens [S] uint32; sync() before reading"""
+        _chk(self.lib.ferhip_copy_rbsp(self.ctx, C.c_void_p(int(dst.ctypes.data if hasattr(dst, "ctypes") else dst.data_ptr())),
+                                       int(dst.strides[0] if hasattr(dst, "strides") else dst.stride(0)), nbytes,
+                                       C.c_void_p(int(lens.ctypes.data if hasattr(lens, "ctypes") else lens.data_ptr())), 1),
+             "ferhip_copy_rbsp")
+
+    def sync(self):
+        _chk(self.lib.ferhip_sync(self.ctx), "ferhip_sync")
 
     def get_recon(self):
         out = np.empty((self.S, self.fsz), np.uint8)
@@ -227,6 +256,77 @@ def inverse_residual(qp, blocks, keep_dc=False):
     return out
 
 
+class Decoder:
+    """Streaming decoder for one stream: RBSP_decode(NALunit), NAL unit by NAL unit (ferhip_dec_*)."""
+
+    def __init__(self):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        _chk(self.lib.ferhip_dec_create(C.byref(self.h)), "ferhip_dec_create")
+        self.W = self.H = 0
+
+    def nal(self, nal_unit_type, nal_ref_idc, rbsp):
+        """-> decoded picture (uint8 [W*H*3/2]) for slice NAL units, else None"""
+        r = np.frombuffer(rbsp, np.uint8)
+        got, W, H = C.c_int(), C.c_int(), C.c_int()
+        pic = np.empty(self.W * self.H * 3 // 2, np.uint8) if nal_unit_type in (1, 5) else None
+        _chk(self.lib.ferhip_dec_nal(self.h, nal_unit_type, nal_ref_idc, r.ctypes.data, len(rbsp),
+                                     pic.ctypes.data if pic is not None else None, C.byref(got), C.byref(W), C.byref(H)),
+             "ferhip_dec_nal")
+        self.W, self.H = W.value, H.value
+        return pic if got.value else None
+
+    def close(self):
+        if self.h:
+            self.lib.ferhip_dec_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def unescape_nal(nal):
+    """Annex-B NAL unit (start code + header + payload) -> (type, ref_idc, rbsp) like getNAL (F/nal.cpp:68-223)"""
+    body = nal[4:]
+    out = bytearray()
+    z = 0
+    for b in body[1:]:
+        if z >= 2 and b == 3:
+            z = 0
+            continue
+        out.append(b)
+        z = z + 1 if b == 0 else 0
+    return body[0] & 31, (body[0] >> 5) & 3, bytes(out)
+
+
+class Y4MReader:
+    """LoadY4MHeader / ReadFromY4M (F/fileIO.cpp:228-346): centre crop to multiples of 16."""
+
+    def __init__(self, path):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        iw, ih, w, h = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _chk(self.lib.ferhip_y4m_open(C.byref(self.h), str(path).encode(), C.byref(iw), C.byref(ih), C.byref(w), C.byref(h)),
+             "ferhip_y4m_open")
+        self.in_size, self.W, self.H = (iw.value, ih.value), w.value, h.value
+
+    def read(self):
+        pic = np.empty(self.W * self.H * 3 // 2, np.uint8)
+        rc = self.lib.ferhip_y4m_read(self.h, pic.ctypes.data)
+        if rc == 1:
+            return None
+        _chk(rc, "ferhip_y4m_read")
+        return pic
+
+    def close(self):
+        if self.h:
+            self.lib.ferhip_y4m_close(self.h)
+            self.h = C.c_void_p()
+
+
 def decode_streams(streams, max_pictures, want_pictures=True):
     """decode() for a list of Annex-B byte strings of equal picture size -> (recon [T][S][fsz], pictures, W, H).
     want_pictures=False leaves the decoded pictures on the device (recon is None): what tools/bench_decode.py times."""
@@ -239,6 +339,8 @@ def decode_streams(streams, max_pictures, want_pictures=True):
     from . import shard
     sps = [n for n in shard.split_nals(streams[0]) if (n[4] & 31) == 7][0]
     w, h = _sps_size(sps[5:])
+    if max_pictures <= 0:
+        raise FerHipError("decode_streams: max_pictures must be positive (it sizes the output)")
     out = np.empty((max_pictures, S, w * h * 3 // 2), np.uint8) if want_pictures else None
     _chk(lib.ferhip_decode_streams(arr, lens, S, out.ctypes.data if want_pictures else None, max_pictures, pics,
                                    C.byref(W), C.byref(H)), "ferhip_decode_streams")

@@ -40,7 +40,7 @@ typedef struct ferhip_ctx ferhip_ctx;
 /* Parameters of Starter::PostaviParametre (F/fer_h264.cpp:169-178) minus the frame range. */
 typedef struct {
     int qp;          /* _qParameter: QPy of every slice, 10..30 in the reference GUI */
-    int basic;       /* BasicInterEncoding; only 0 is implemented on the GPU */
+    int basic;       /* BasicInterEncoding: 1 = stage 1 of the search only, counters of the discarded exhaustive pass kept */
     int window;      /* WindowSize: +-window/2 integer search, +-window/16 quarter-pel search */
     int maxdiff;     /* MAXDIFF_SET, -1 = adaptive */
     int intra_every; /* IntraEvery */
@@ -73,6 +73,13 @@ int ferhip_select_nal_type(ferhip_ctx *c, int *nal_type_out);
  * words are big-endian bit order, stream s starts at byte s * *stride. */
 int ferhip_encode_picture_dev(ferhip_ctx *c, int *nal_type, const uint8_t **d_rbsp, size_t *stride,
                               const uint32_t **d_rbsp_len);
+
+/* RBSP of the last picture to caller buffers, asynchronously on the context's stream (ordered before the next
+ * picture reuses the device buffer): bytes_per_stream bytes per stream to dst + s * dst_stride, the lengths to
+ * len_dst[S].  host = 1: dst / len_dst are host memory (pinned for a truly asynchronous copy), else device memory. */
+int ferhip_copy_rbsp(ferhip_ctx *c, void *dst, size_t dst_stride, size_t bytes_per_stream, uint32_t *len_dst, int host);
+/* waits for everything the context has enqueued */
+int ferhip_sync(ferhip_ctx *c);
 
 /* reconstruction of the last encoded picture, [nstreams][W*H*3/2]; host = 1 copies D2H */
 int ferhip_get_recon(ferhip_ctx *c, void *dst, int host);
@@ -151,6 +158,33 @@ int ferhip_set_reference(ferhip_ctx *c, const void *src);
  * implement (sub-8x8 partitions, I_PCM, several reference indices) returns FERHIP_E_UNSUP. */
 int ferhip_decode_streams(const uint8_t *const *streams, const size_t *lens, int nstreams, uint8_t *out,
                           int max_pictures, int *pictures, int *width, int *height);
+/* frees the window buffers ferhip_decode_streams keeps between calls (tens of GB for large batches); FERHIP_E_STATE
+ * while a decode is running */
+int ferhip_decode_release(void);
+
+/* ---- streaming decoder: RBSP_decode(NALunit) of F/rbsp_decoding.cpp:17 for one stream, NAL unit by NAL unit ----
+ * rbsp = the NAL unit's payload without header byte and emulation prevention bytes (what getNAL delivers,
+ * F/nal.cpp:68-223).  nal_unit_type 7 (SPS) sizes the decoder, 8 (PPS) is kept, 5 / 1 decode one picture: when
+ * `picture` is not NULL it receives W*H*3/2 bytes of I420 and *got_picture = 1.  Other NAL unit types are ignored. */
+typedef struct ferhip_dec ferhip_dec;
+int ferhip_dec_create(ferhip_dec **out);
+int ferhip_dec_nal(ferhip_dec *d, int nal_unit_type, int nal_ref_idc, const uint8_t *rbsp, size_t n, uint8_t *picture,
+                   int *got_picture, int *width, int *height);
+void ferhip_dec_destroy(ferhip_dec *d);
+
+/* ---- Y4M ingest (row f3): LoadY4MHeader / ReadFromY4M of F/fileIO.cpp:228-346 without the globals ----
+ * The picture size comes from the header's " W" / " H" tokens; coded size = cropped to multiples of 16 around the
+ * centre.  ferhip_y4m_read fills one coded-size I420 picture (use pinned memory when it feeds ferhip_set_frames);
+ * returns 0, or 1 at the end of the stream. */
+typedef struct ferhip_y4m ferhip_y4m;
+int ferhip_y4m_open(ferhip_y4m **out, const char *path, int *in_width, int *in_height, int *coded_width, int *coded_height);
+int ferhip_y4m_read(ferhip_y4m *y, unsigned char *dst);
+void ferhip_y4m_close(ferhip_y4m *y);
+/* emit, F/fileIO.cpp:100-176: the stream header "YUV4MPEG2 C420jpeg W%d H%d F24:1 Ip A1:1\n" and one picture
+ * ("FRAME\n" + I420 when with_frame_line, bare I420 = writeToYUV otherwise); file = a FILE* */
+int ferhip_y4m_write_header(void *file, int width, int height);
+int ferhip_y4m_write_frame(void *file, const unsigned char *i420, int width, int height, int with_frame_line);
+
 /* ---- block-level KAT surface: the reference's own signatures as batched device calls ----
  * forwardResidual(qP, c, r, Intra, Intra16x16OrChroma), F/quantizationTransform.h:
  * n blocks of 16 int32 (raster) in, 16 int32 out. */

@@ -14,6 +14,8 @@
  *   int _qParameter, BasicInterEncoding, WindowSize, MAXDIFF_SET, IntraEvery, currFrameCount
  *                                                                                            F/h264_globals.h:168-176,193
  *   int brojTipova[5], vrijeme                                                               F/h264_globals.h:166-167
+ *   void RBSP_decode(NALunit nal_unit)               void RBSP_decode(NALunit nal_unit)      F/rbsp_decoding.h:3
+ *   LoadY4MHeader / ReadFromY4M / writeToY4M / writeToYUV, FILE *yuvinput, *yuvoutput        F/fileIO.h
  *
  * Contract kept from F/rbsp_encoding.cpp:119-326: nal_unit_type 7 / 8 write SPS / PPS (the SPS
  * call also sizes the encoder from frame.Lwidth x frame.Lheight); 5 / 1 encode the picture in
@@ -48,6 +50,20 @@ extern int vrijeme; /* clock() ticks spent in the last picture */
 
 void RBSP_encode(NALunit *nal_unit);
 int selectNALUnitType(void);
+
+/* void RBSP_decode(NALunit nal_unit), F/rbsp_decoding.h:3 (by value, as in the reference): the callee of decode()'s
+ * getNAL loop (F/fer_h264.cpp:37-47).  nal_unit_type 7 sizes and allocates `frame`, 8 takes the PPS, 5 / 1 decode one
+ * picture into `frame` (it becomes the reference picture) and append it to `yuvoutput` when that file is open. */
+void RBSP_decode(NALunit nal_unit);
+
+/* Y4M ingest / emit of F/fileIO.h, through `frame`, `yuvinput` and `yuvoutput` (F/fileIO.cpp:10-11,100-176,228-346) */
+#include <stdio.h>
+extern FILE *yuvinput, *yuvoutput;
+extern int inputWidth, inputHeight;
+void LoadY4MHeader(void);
+int ReadFromY4M(void);
+void writeToY4M(void);
+void writeToYUV(void);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ int *fo_dbg_mv(fo_ctx *c, int y) { return y ? &c->dbg_mvy[0][0][0] : &c->dbg_mvx
 int *fo_dbg_tc_l(fo_ctx *c) { return &c->tc_l[0][0]; }
 int *fo_dbg_tc_c(fo_ctx *c) { return &c->tc_c[0][0][0]; }
 int *fo_dbg_i4mode(fo_ctx *c) { return c->i4mode; }
+int *fo_dbg_type_count(fo_ctx *c) { return c->type_count; } /* brojTipova */
 void fo_dbg_set_dpb(fo_ctx *c, const uint8_t *y, const uint8_t *u, const uint8_t *v)
 {
     memcpy(c->dL, y, (size_t)c->W * c->H);

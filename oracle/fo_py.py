@@ -40,7 +40,7 @@ def lib():
             getattr(L, n).argtypes = [vp, i]
         L.fo_dbg_kar.restype = vp
         L.fo_dbg_kar.argtypes = [vp, i, i]
-        for n in ("fo_dbg_koliko", "fo_dbg_mb_type", "fo_dbg_tc_l", "fo_dbg_tc_c", "fo_dbg_i4mode"):
+        for n in ("fo_dbg_koliko", "fo_dbg_mb_type", "fo_dbg_tc_l", "fo_dbg_tc_c", "fo_dbg_i4mode", "fo_dbg_type_count"):
             getattr(L, n).restype = vp
             getattr(L, n).argtypes = [vp]
         L.fo_dbg_set_dpb.argtypes = [vp, vp, vp, vp]
@@ -125,6 +125,10 @@ class Oracle:
         x = _arr(self.L.fo_dbg_mv(self.c, 0), self.nmb * 16, np.int32).reshape(self.nmb, 4, 4)[:, :, 0]
         y = _arr(self.L.fo_dbg_mv(self.c, 1), self.nmb * 16, np.int32).reshape(self.nmb, 4, 4)[:, :, 0]
         return np.stack([x, y], -1).copy()
+
+    def stats(self):
+        """brojTipova[5]: P_Skip, 16x16, 16x8, 8x16, 8x8 macroblocks so far"""
+        return _arr(self.L.fo_dbg_type_count(self.c), 5, np.int32).copy()
 
     def cbp(self):
         return np.stack([_arr(self.L.fo_dbg_cbp(self.c, k), self.nmb, np.int32) for k in range(2)], -1).copy()

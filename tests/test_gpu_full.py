@@ -34,12 +34,15 @@ def _check_against_oracle(pkg, fo, W, H, T, S, qp, window, intra_every, noise=2,
     g = pkg.FerHip(W, H, S, qp=qp, window=window, maxdiff=3, intra_every=intra_every)
     streams, rec = g.encode_streams(frames, want_recon=True)
     assert g.status() == [0] * S
+    counts = g.stats()
     for s in check_streams:
         o = fo.Oracle(W, H, qp=qp, window=window, maxdiff=3, intra_every=intra_every)
         ref, ref_rec = o.encode_stream(frames[:, s])
+        ref_counts = o.stats()
         o.close()
         assert np.array_equal(rec[:, s], ref_rec), f"recon of stream {s}"
         assert streams[s] == ref, f"bitstream of stream {s}"
+        assert list(counts[s]) == list(ref_counts), f"brojTipova of stream {s}"
     # property: the oracle DEcoder turns the GPU bitstream back into the GPU reconstruction
     n, dec, _ = fo.decode_stream_md5(streams[-1])
     assert n == T
@@ -226,7 +229,32 @@ def test_bad_arguments_are_rejected(pkg):
     with pytest.raises(pkg.FerHipError):
         pkg.FerHip(100, 144, 1)          # not a multiple of 16
     with pytest.raises(pkg.FerHipError):
-        pkg.FerHip(176, 144, 1, basic=1)  # BasicInterEncoding is not implemented on the GPU
+        pkg.FerHip(176, 144, 0)          # no streams
+
+
+@pytest.mark.parametrize("W,H,T,qp,window,noise", [(176, 144, 5, 12, 16, 2), (176, 144, 4, 28, 32, 0), (1920, 1072, 3, 12, 32, 2)])
+def test_basic_inter_encoding_matches_oracle(pkg, fo, W, H, T, qp, window, noise):
+    """BasicInterEncoding = 1 (F/moestimation.cpp:394-397,470): the exhaustive pass whose vectors the reference
+    discards leaves only brojTipova behind; stages 2 and 3 of the feature search are skipped.  Bitstream,
+    reconstruction and the counters (P_Skip counted twice, the discarded pass's own 16x16 / 8x8 verdicts) must be
+    the oracle's."""
+    S = 2
+    frames = np.stack([np.stack([pkg.gen_frame(W, H, t, 99 + s, noise) for s in range(S)]) for t in range(T)])
+    g = pkg.FerHip(W, H, S, qp=qp, window=window, maxdiff=3, intra_every=30, basic=1)
+    streams, rec = g.encode_streams(frames, want_recon=True)
+    assert g.status() == [0] * S
+    st = g.stats()
+    g.close()
+    for s in range(S):
+        o = fo.Oracle(W, H, qp=qp, window=window, maxdiff=3, intra_every=30, basic=1)
+        ref, ref_rec = o.encode_stream(frames[:, s])
+        cnt = o.stats()
+        o.close()
+        assert streams[s] == ref, f"bitstream of stream {s}"
+        assert np.array_equal(rec[:, s], ref_rec)
+        assert list(st[s]) == list(cnt), f"brojTipova of stream {s}: {st[s]} vs {cnt}"
+    if noise == 0:
+        assert st[0][0] > 0 and st[0][0] % 2 == 0   # P_Skip macroblocks, each counted twice
 
 
 def test_legacy_global_seam_matches_oracle(pkg, fo):
@@ -327,3 +355,127 @@ def test_gpu_decoder_reproduces_reference_md5_on_drugi(pkg):
         h.update(b"FRAME\n")
         h.update(out[t, 0].tobytes())
     assert h.hexdigest() == "346891974ac8cafcc6bb72706e34f950"
+
+
+def test_streaming_decoder_nal_by_nal(pkg, fo):
+    """ferhip_dec_nal: one stream fed NAL unit by NAL unit (what RBSP_decode does), against the oracle decoder."""
+    for case in ["qcif_ippp_4f_qp12_w16", "qcif_skip_5f_qp12"]:
+        stream = (GOLD / f"{case}.264").read_bytes()
+        ref = _oracle_decode(fo, stream)
+        d = pkg.Decoder()
+        pics = []
+        for nal in pkg.split_nals(stream):
+            t, idc, rbsp = pkg.unescape_nal(nal)
+            p = d.nal(t, idc, rbsp)
+            if p is not None:
+                pics.append(p)
+        d.close()
+        assert (d.W, d.H) == (176, 144)
+        assert np.array_equal(np.stack(pics), ref), case
+
+
+def test_legacy_rbsp_decode_seam(pkg, tmp_path):
+    """The reference's decode() loop (F/fer_h264.cpp:26-53): getNAL -> RBSP_decode(nu), output appended to `yuvoutput`
+    by writeToY4M.  Driven through the exported legacy names on the reference's own fixture drugi.264 (first 40
+    pictures NAL by NAL) and checked against the batch decoder, whose whole-file md5 is the reference's."""
+    import ctypes as C
+    lib = pkg.load_library()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+
+    class NALunit(C.Structure):
+        _fields_ = [("forbidden_zero_bit", C.c_ubyte), ("nal_ref_idc", C.c_uint), ("nal_unit_type", C.c_uint),
+                    ("NumBytesInRBSP", C.c_uint), ("rbsp_byte", C.POINTER(C.c_ubyte))]
+
+    lib.RBSP_decode.argtypes = [NALunit]
+    lib.RBSP_decode.restype = None
+    stream = (GOLD / "drugi.264").read_bytes()
+    NP = 40
+    nals = pkg.split_nals(stream[:4_000_000])
+    want, pics, W, H = pkg.decode_streams([stream], NP)
+    assert pics == [NP]
+    out = tmp_path / "dec.y4m"
+    lib.ferhip_fileio_reset()
+    fout = libc.fopen(str(out).encode(), b"wb")
+    C.c_void_p.in_dll(lib, "yuvoutput").value = fout
+    buf = (C.c_ubyte * 500000)()
+    n = 0
+    for nal in nals:
+        t, idc, rbsp = pkg.unescape_nal(nal)
+        if t in (1, 5):
+            if n == NP:
+                break
+            n += 1
+        C.memmove(buf, rbsp, len(rbsp))
+        lib.RBSP_decode(NALunit(0, idc, t, len(rbsp), C.cast(buf, C.POINTER(C.c_ubyte))))
+    libc.fclose(fout)
+    C.c_void_p.in_dll(lib, "yuvoutput").value = None
+    lib.ferhip_fileio_reset()
+    expect = b"YUV4MPEG2 C420jpeg W%d H%d F24:1 Ip A1:1\n" % (W, H) + b"".join(b"FRAME\n" + want[t, 0].tobytes() for t in range(NP))
+    assert out.read_bytes() == expect
+
+
+def test_decoder_batch_with_different_qp_per_stream(pkg, fo):
+    """Streams of one decode call carry their own PPS: the QP of this codec lives there (pic_init_qp = 14 + qp,
+    slice_qp_delta = -14, F/headers_and_parameter_sets.cpp:489,186)."""
+    W, H, T = 176, 144, 3
+    frames = np.stack([pkg.gen_frame(W, H, t, 4, 2) for t in range(T)])
+    streams = []
+    for qp in (12, 28, 20):
+        o = fo.Oracle(W, H, qp=qp, window=16, maxdiff=3, intra_every=30)
+        s, _ = o.encode_stream(frames)
+        o.close()
+        streams.append(s)
+    out, pics, w, h = pkg.decode_streams(streams, T)
+    assert pics == [T] * 3
+    for k, s in enumerate(streams):
+        assert np.array_equal(out[:, k], _oracle_decode(fo, s)), k
+    with pytest.raises(pkg.FerHipError):
+        pkg.decode_streams(streams, 0)   # the output buffer is sized by max_pictures
+
+
+def test_device_path_with_explicit_types_back_to_back(pkg, fo):
+    """ferhip_encode_picture_dev with explicit picture types never synchronises between pictures: the slice headers
+    of consecutive pictures must not overwrite each other in the pinned staging buffer (header ring).  Same pictures
+    through the device-input / device-output path of two contexts driven from two threads (what bench.py times)
+    against the oracle."""
+    import threading
+    import torch
+    W, H, T, S = 176, 144, 6, 2
+    types = [pkg.ferhip.NAL_IDR if t % 3 == 0 else pkg.ferhip.NAL_SLICE for t in range(T)]
+    res = {}
+
+    def run(k):
+        frames = np.stack([np.stack([pkg.gen_frame(W, H, t, 40 + 10 * k + s, 2) for s in range(S)]) for t in range(T)])
+        dev = torch.from_numpy(frames).cuda()
+        g = pkg.FerHip(W, H, S, qp=16, window=16, maxdiff=3, intra_every=1000)
+        stride = g.nmb * 1024 + 4096
+        keep = torch.empty((T, S, stride), dtype=torch.uint8, device="cuda")
+        lens = torch.empty((T, S), dtype=torch.int32, device="cuda")
+        st = torch.cuda.Stream()
+        for t in range(T):
+            g.set_frames_device(dev[t].data_ptr())
+            p, strd, pl, nt = g.encode_picture_device([types[t]] * S)
+            assert strd == stride and nt == [types[t]] * S
+            # the library's stream is not torch's: order the copies behind the picture with a full status read at the end
+            g.copy_rbsp_device(keep[t].data_ptr(), lens[t].data_ptr())
+        assert g.status() == [0] * S
+        res[k] = (frames, keep.cpu().numpy(), lens.cpu().numpy(), g)
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for k in range(2):
+        frames, keep, lens, g = res[k]
+        sps, pps = g.sps_pps()
+        for s in range(S):
+            o = fo.Oracle(W, H, qp=16, window=16, maxdiff=3, intra_every=3)
+            ref, _ = o.encode_stream(frames[:, s])
+            o.close()
+            got = sps + pps + b"".join(g.write_nal(types[t], keep[t, s, : lens[t, s]].tobytes()) for t in range(T))
+            assert got == ref, (k, s)
+        g.close()

@@ -116,3 +116,74 @@ def test_two_rank_gloo_gop_sharding(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "OK" in outs[0]
+
+
+def _write_y4m(path, W, H, frames, params=False):
+    with open(path, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F25:1 Ip A1:1 C420jpeg\n" % (W, H))
+        for k, fr in enumerate(frames):
+            f.write(b"FRAME Ix\n" if (params and k == 1) else b"FRAME\n")
+            f.write(fr.tobytes())
+
+
+def test_y4m_reader_crops_like_the_reference(pkg, tmp_path):
+    """ferhip_y4m_* = LoadY4MHeader / ReadFromY4M (F/fileIO.cpp:228-346): size from the W / H tokens, centre crop to
+    multiples of 16 (chroma at half the offsets), end of stream on a short read."""
+    W, H, T = 100, 70, 3
+    frames = [pkg.gen_frame(W, H, t, 3, 2) for t in range(T)]
+    p = tmp_path / "a.y4m"
+    _write_y4m(p, W, H, frames, params=True)
+    with open(p, "ab") as f:
+        f.write(b"FRAME\n" + b"\x00" * 100)   # a truncated picture ends the stream
+    r = pkg.Y4MReader(p)
+    assert r.in_size == (W, H) and (r.W, r.H) == (96, 64)
+    for t in range(T):
+        want, w, h = pkg.crop_to_mb(frames[t], W, H)
+        got = r.read()
+        assert got is not None and np.array_equal(got, want), t
+    assert r.read() is None
+    r.close()
+
+
+def test_legacy_file_io_names(pkg, tmp_path):
+    """The reference's own names (LoadY4MHeader, ReadFromY4M, writeToY4M, writeToYUV over `frame`, `yuvinput`,
+    `yuvoutput`, F/fileIO.h) as exported by libferhip.so: read a Y4M, write it back, compare bytes."""
+    lib = pkg.load_library()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+
+    class Frame(C.Structure):
+        _fields_ = [("Lwidth", C.c_int), ("Lheight", C.c_int), ("Cwidth", C.c_int), ("Cheight", C.c_int),
+                    ("L", C.POINTER(C.c_ubyte)), ("C", C.POINTER(C.c_ubyte) * 2)]
+
+    W, H, T = 64, 48, 2
+    frames = [pkg.gen_frame(W, H, t, 8, 1) for t in range(T)]
+    src, dst = tmp_path / "in.y4m", tmp_path / "out.y4m"
+    _write_y4m(src, W, H, frames)
+    lib.ferhip_fileio_reset()
+    frame = Frame.in_dll(lib, "frame")
+    frame.L = None
+    frame.C[0] = None
+    frame.C[1] = None
+    fin = libc.fopen(str(src).encode(), b"rb")
+    fout = libc.fopen(str(dst).encode(), b"wb")
+    C.c_void_p.in_dll(lib, "yuvinput").value = fin
+    C.c_void_p.in_dll(lib, "yuvoutput").value = fout
+    lib.LoadY4MHeader()
+    assert (frame.Lwidth, frame.Lheight, frame.Cwidth, frame.Cheight) == (W, H, W // 2, H // 2)
+    assert C.c_int.in_dll(lib, "inputWidth").value == W
+    n = 0
+    while lib.ReadFromY4M() != -1:
+        assert bytes(frame.L[: W * H]) == frames[n][: W * H].tobytes()
+        lib.writeToY4M()
+        n += 1
+    assert n == T
+    libc.fclose(fin)
+    libc.fclose(fout)
+    C.c_void_p.in_dll(lib, "yuvinput").value = None
+    C.c_void_p.in_dll(lib, "yuvoutput").value = None
+    want = b"YUV4MPEG2 C420jpeg W%d H%d F24:1 Ip A1:1\n" % (W, H) + b"".join(b"FRAME\n" + f.tobytes() for f in frames)
+    assert dst.read_bytes() == want
+    lib.ferhip_fileio_reset()
