@@ -1,48 +1,117 @@
 #!/usr/bin/env python3
-"""bench.py -- macroblocks/sec of the 1080p IPPP encode hot path on MI355X.
+"""bench.py -- macroblocks/sec of the fer_h264 encode hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 1920x1080 4:2:0
-synthetic input, coded 1920x1072 (the reference crops to multiples of 16), IPPP with
-IntraEvery = 30, qp 12, WindowSize 32 (+-16 integer search, +-2 quarter-pel search),
-MAXDIFF 3, BasicInterEncoding 0.  One "step" = one closed GOP of 30 pictures for every one of
-the S independent streams resident on the GPU (input pictures already in HBM; the RBSP stays in
-HBM).  Ranks (one per GPU) encode disjoint stream sets, no data-path collective: weak scaling.
+Default workload (BASELINE.json configs[2], the configuration the metric is quoted on): 1920x1080 4:2:0 synthetic
+input, coded 1920x1072 (the reference crops to multiples of 16), IPPP with IntraEvery = 30, qp 12, WindowSize 32
+(+-16 integer search, +-2 quarter-pel search), MAXDIFF 3, BasicInterEncoding 0.  One "step" = one closed GOP of 30
+pictures for every one of the S independent streams resident on the GPU (input pictures already in HBM; the RBSP
+stays in HBM).  Ranks (one per GPU) encode disjoint stream sets, no data-path collective: weak scaling.
 
-Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (dominant kernel, live HIP
-event timing from the library's launch stream) and `cpu_baseline` (the CPU oracle, test
-infrastructure, timed on a bounded sample of the same workload on this host).
+`--config 4k` is BASELINE configs[3]: 3840x2160, 64 pictures = 8 closed GOPs of 8 (qp 28, WindowSize 32), the GOPs
+sharded over the ranks (gops_of_rank), each rank encoding its GOPs with libferhip, the host merging the NAL units in
+GOP order; the SHA-256 of the merged stream is checked against the committed oracle value (strong scaling: the
+total work is fixed).
+
+`--gpus N` (N > 1) without a launcher: this process starts N rank processes itself (before any GPU call) and relays
+rank 0's line.  Under `python -m torch.distributed.run` the ranks come from the environment.
+
+Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (dominant kernel, live HIP event timing on the
+library's launch stream), `cpu_baseline` (the CPU oracle -- test infrastructure -- timed on a bounded sample of the
+same workload on this host) and the extra figures SURVEY.md 8d asks for (PCIe-inclusive rate, integer-VALU fraction,
+P_Skip fraction, N-process CPU baseline, output hash check, secondary configurations).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
+import threading
 import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "tests"))
 
-W, H_IN, H = 1920, 1080, 1072
-GOP = 30
-QP, WINDOW, MAXDIFF = 12, 32, 3
 ME_BYTES_PER_MB = 528          # 256 B current luma + 256 B reference luma + 16 B MVs
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_LANE_OPS = 78.6e12        # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+LANE_OPS_PER_MB = 2.1e5        # the reference-exact search at WindowSize 32
+
+CONFIGS = {
+    "1080p": dict(W=1920, H_in=1080, H=1072, gop=30, qp=12, window=32, maxdiff=3, scaling="weak",
+                  workload="1080p IPPP encode, full-search +-16 ME (BASELINE configs[2])"),
+    "4k": dict(W=3840, H_in=2160, H=2160, gop=8, ngops=8, qp=28, window=32, maxdiff=3, scaling="strong",
+               workload="4K 3840x2160 IPPP encode, 64 pictures = 8 closed GOPs of 8 sharded over the ranks "
+                        "(BASELINE configs[3])"),
+}
+
+# phase -> (kernel, algorithmic bytes per macroblock, limiter, runs on "P" / "I" / "all" pictures)
+KERNELS = {
+    "interp": ("k_interp", 256 + 16 * 256, "hbm", "P"),
+    "features": ("k_features", 16 * 256 + 256 * (192 + 12), "hbm", "P"),
+    "sort_keys": ("k_sort_keys", 256 * (2 + 8), "hbm", "P"),
+    "sort": ("k_rs_hist+k_rs_scan+k_rs_scatter (two radix passes)", 2 * 256 * (4 + 8 + 8), "hbm", "P"),
+    "sort_finish": ("k_sort_finish", 256 * (8 + 12 + 16), "hbm", "P"),
+    "me_pre": ("k_me_pre", ME_BYTES_PER_MB, "valu", "P"),
+    "me_walk": ("k_me_walk", ME_BYTES_PER_MB, "valu", "P"),
+    "me_resolve": ("k_me_resolve", ME_BYTES_PER_MB, "valu", "P"),
+    "p_resid": ("k_p_resid", 1152, "hbm", "P"),
+    "intra": ("k_intra_mb", 768, "latency", "I"),
+    "cavlc": ("k_cavlc", 800, "hbm", "all"),
+    "frame_sad": ("k_frame_sad", 512, "hbm", "P"),
+}
 
 
-def cpu_baseline(frames_np, nframes):
-    """CPU oracle (oracle/fo_cli, a bit-exact port, kind 'port') on the first `nframes` pictures
-    of stream 0: one process = one core, like the single-threaded reference."""
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """Parent of an N-rank run: never touches the GPU; children get RANK / WORLD_SIZE / LOCAL_RANK."""
+    n = args.gpus
+    port = free_port()
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), FER_BENCH_CHILD="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = procs[0].communicate()[0]
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if any(rcs) or line is None:
+        sys.stderr.write(out0 or "")
+        raise SystemExit(f"rank processes failed: return codes {rcs}")
+    print(line, flush=True)
+
+
+def run_oracle_enc(cfg, frames_np, nframes, tag):
+    """oracle/fo_cli (a bit-exact port of the reference, kind 'port') on `nframes` pictures: one process = one core."""
     cli = ROOT / "oracle" / "fo_cli"
     if not cli.exists():
         subprocess.run(["make", "-s", "-C", str(ROOT / "oracle"), "fo_cli"], check=True)
-    tmp = Path(os.environ.get("TMPDIR", "/tmp")) / f"ferbench_{os.getpid()}"
+    tmp = Path(os.environ.get("TMPDIR", "/tmp")) / f"ferbench_{os.getpid()}_{tag}"
     tmp.mkdir(parents=True, exist_ok=True)
     src = tmp / "in.yuv"
     frames_np[:nframes].tofile(src)
-    out = subprocess.run([str(cli), "enc", str(W), str(H), str(nframes), str(QP), str(WINDOW), str(MAXDIFF),
-                          str(GOP), "0", str(src), str(tmp / "out.264")], check=True, capture_output=True, text=True)
-    res = json.loads(out.stdout.strip().splitlines()[-1])
+    cmd = [str(cli), "enc", str(cfg["W"]), str(cfg["H"]), str(nframes), str(cfg["qp"]), str(cfg["window"]),
+           str(cfg["maxdiff"]), str(cfg["gop"]), "0", str(src), str(tmp / "out.264")]
+    return subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True), tmp
+
+
+def finish_oracle(proc, tmp):
+    out = proc.communicate()[0]
+    res = json.loads(out.strip().splitlines()[-1])
     for f in tmp.iterdir():
         f.unlink()
     tmp.rmdir()
@@ -54,13 +123,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="1080p")
+    ap.add_argument("--content", choices=["textured", "letterbox", "flat-half", "still"], default="textured",
+                    help="synthetic content variant: letterbox = 128 black-ish rows top and bottom, flat-half = left half one "
+                         "value (large flat areas), still = no motion and no noise (P_Skip heavy)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("FER_BENCH_STREAMS", "128")))
-    ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("FER_BENCH_STAGGER_MS", "0")),
-                    help="start offset between consecutive contexts (milliseconds)")
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("FER_BENCH_CONTEXTS", "2")),
                     help="encoder contexts per GPU, each on its own HIP stream and host thread (streams are split evenly)")
     ap.add_argument("--cpu-frames", type=int, default=3, help="pictures of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--secondary", type=int, default=1, help="also time configs[1] (720p I-only) and configs[4] (decode)")
+    ap.add_argument("--e2e", type=int, default=1, help="also time the PCIe-inclusive path (pinned host pictures in, host RBSP out)")
+    ap.add_argument("--dist-backend", default=os.environ.get("FER_BENCH_BACKEND", "nccl"),
+                    help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal: several ranks may share GPU 0)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1 and "FER_BENCH_CHILD" not in os.environ:
+        return spawn_ranks(args, sys.argv[1:])
 
     import numpy as np
     import torch
@@ -68,61 +147,98 @@ def main():
     from conftest import load_pkg
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "gloo":
+        local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
+    cfg = CONFIGS[args.config]
+    W, H_IN, H, GOP = cfg["W"], cfg["H_in"], cfg["H"], cfg["gop"]
     pkg = load_pkg()
     from h264_fer_amd.synth import gen_frames_torch
-    S = args.streams
-    # one GOP of distinct content per stream (seed differs per stream and per rank), resident in HBM
-    frames = gen_frames_torch(W, H_IN, GOP, S, dev, seed=1234 + 1000 * rank, noise=2)
-    # centre crop 1080 -> 1072 like ReadFromY4M (F/fileIO.cpp:290-333)
+
+    if args.config == "4k":
+        # 64 pictures of ONE sequence; GOP g = pictures 8g .. 8g+7, encoded as its own stream by rank g % world
+        mine = pkg.gops_of_rank(cfg["ngops"], world, rank)
+        S = len(mine)
+        if S == 0:
+            raise SystemExit("more ranks than GOPs")
+        frames = gen_frames_torch(W, H_IN, GOP, S, dev, noise=2, seeds=[1234] * S, t0s=[g * GOP for g in mine])
+        total_streams = cfg["ngops"]
+    else:
+        S = args.streams
+        mine = None
+        # one GOP of distinct content per stream (seed differs per stream and per rank), resident in HBM
+        still = args.content == "still"
+        frames = gen_frames_torch(W, H_IN, GOP, S, dev, seed=1234 + 1000 * rank, noise=0 if still else 2)
+        if still:
+            frames[1:] = frames[0:1]
+        total_streams = world * S
     ys = W * H_IN
-    Y = frames[:, :, :ys].view(GOP, S, H_IN, W)[:, :, 4:4 + H, :]
-    U = frames[:, :, ys:ys + ys // 4].view(GOP, S, H_IN // 2, W // 2)[:, :, 2:2 + H // 2, :]
-    V = frames[:, :, ys + ys // 4:].view(GOP, S, H_IN // 2, W // 2)[:, :, 2:2 + H // 2, :]
+    Yp = frames[:, :, :ys].view(GOP, S, H_IN, W)
+    if args.content == "letterbox":
+        Yp[:, :, :132] = 16
+        Yp[:, :, -132:] = 16
+    elif args.content == "flat-half":
+        Yp[:, :, :, : W // 2] = 100
+    # centre crop like ReadFromY4M (F/fileIO.cpp:290-333)
+    ct = (H_IN - H) // 2
+    Y = Yp[:, :, ct:ct + H, :]
+    U = frames[:, :, ys:ys + ys // 4].view(GOP, S, H_IN // 2, W // 2)[:, :, ct // 2:ct // 2 + H // 2, :]
+    V = frames[:, :, ys + ys // 4:].view(GOP, S, H_IN // 2, W // 2)[:, :, ct // 2:ct // 2 + H // 2, :]
     frames = torch.cat([Y.reshape(GOP, S, -1), U.reshape(GOP, S, -1), V.reshape(GOP, S, -1)], dim=2).contiguous()
+    del Y, U, V, Yp
     torch.cuda.synchronize()
 
-    # The streams are split over `contexts` encoder contexts, each with its own HIP stream and host
-    # thread: while one context sits in its latency-bound per-diagonal launches, the other fills the
-    # CUs with its throughput-bound kernels (the streams are independent, so this is pure overlap).
-    import threading
+    # The streams are split over `contexts` encoder contexts, each with its own HIP stream and host thread: while one
+    # context's host thread waits for its 8-byte frame-SAD read-back, the other keeps the GPU fed.
     NC = max(1, min(args.contexts, S))
     bounds = [S * i // NC for i in range(NC + 1)]
     parts = [frames[:, bounds[i]:bounds[i + 1]].contiguous() for i in range(NC)]
     del frames
     torch.cuda.synchronize()
-    encs = [pkg.FerHip(W, H, bounds[i + 1] - bounds[i], qp=QP, window=WINDOW, maxdiff=MAXDIFF, intra_every=GOP)
-            for i in range(NC)]
-    enc = encs[0]
-    nmb = enc.nmb
+    encs = [pkg.FerHip(W, H, bounds[i + 1] - bounds[i], qp=cfg["qp"], window=cfg["window"], maxdiff=cfg["maxdiff"],
+                       intra_every=GOP) for i in range(NC)]
+    nmb = encs[0].nmb
+    fsz = W * H * 3 // 2
 
-    def run_ctx(i):
+    def run_ctx(i, sink=None):
         e, fr = encs[i], parts[i]
-        if i and args.stagger_ms > 0:
-            # contexts that run in lockstep compete for the same unit (HBM in the feature pass, VALU in the search);
-            # a start offset of a fraction of a picture puts one context's memory-bound kernels under the other's
-            # compute-bound ones.  The offset is inside the timed region.
-            time.sleep(i * args.stagger_ms / 1e3)
         for t in range(GOP):
             e.set_frames_device(fr[t].data_ptr())
-            e.encode_picture_device(None)   # AUTO: selectNALUnitType semantics (IDR every GOP)
+            _, _, _, nt = e.encode_picture_device(None)   # AUTO: selectNALUnitType semantics (IDR every GOP)
+            if sink is not None:
+                sink(i, t, nt)
 
-    def step():
+    def threaded(fn):
         if NC == 1:
-            return run_ctx(0)
-        th = [threading.Thread(target=run_ctx, args=(i,)) for i in range(NC)]
+            return fn(0)
+        err = []
+
+        def wrap(i):
+            try:
+                fn(i)
+            except BaseException as ex:  # noqa: BLE001 -- reported after the join
+                err.append(ex)
+        th = [threading.Thread(target=wrap, args=(i,)) for i in range(NC)]
         for x in th:
             x.start()
         for x in th:
             x.join()
+        if err:
+            raise err[0]
+
+    def step():
+        threaded(run_ctx)
 
     def sync():
         torch.cuda.synchronize()
@@ -132,6 +248,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    stats0 = [e.stats().copy() for e in encs]
     for e in encs:
         e.get_profile(reset=True)
         e.profile(True)
@@ -152,76 +269,222 @@ def main():
     if any(status):
         raise SystemExit(f"device error flags {status}")
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    counts = sum((e.stats() - s0).sum(axis=0) for e, s0 in zip(encs, stats0))   # brojTipova over the timed steps
 
-    total_mbs = world * S * GOP * nmb * args.steps
+    total_mbs = total_streams * GOP * nmb * args.steps
     value = total_mbs / dt
 
-    # roofline of the dominant kernel (by accumulated device time; every profiled phase is one kernel, except
+    # ---- output check: one more (untimed) GOP through the very path that was timed -- device pictures in, two
+    # contexts on two host threads, ferhip_encode_picture_dev -- with the RBSP of every picture read back; stream 0
+    # (1080p) or the merged GOP streams (4k) hashed and compared with the committed oracle value
+    cap = 2 << 20
+    host_rbsp = [torch.empty((GOP, encs[i].S, cap), dtype=torch.uint8).pin_memory() for i in range(NC)]
+    host_len = [torch.zeros((GOP, encs[i].S), dtype=torch.int32).pin_memory() for i in range(NC)]
+    nal_types = [[None] * GOP for _ in range(NC)]
+
+    def grab(i, t, nt):
+        encs[i].copy_rbsp_host(host_rbsp[i][t], host_len[i][t], cap)
+        nal_types[i][t] = nt
+
+    threaded(lambda i: run_ctx(i, grab))
+    for e in encs:
+        e.sync()
+
+    def annexb(i, s):
+        sps, pps = encs[i].sps_pps()
+        out = bytearray(sps + pps)
+        for t in range(GOP):
+            n = int(host_len[i][t, s])
+            if n > cap:
+                raise SystemExit("RBSP larger than the read-back window")
+            out += encs[i].write_nal(nal_types[i][t][s], host_rbsp[i][t, s, :n].numpy().tobytes())
+        return bytes(out)
+
+    gold = json.loads((ROOT / "tests" / "golden" / "goldens.json").read_text())
+    check = {"rbsp_sha256": None, "expected": None, "ok": None}
+    if args.config == "4k":
+        local_streams = {}
+        for i in range(NC):
+            for s in range(encs[i].S):
+                local_streams[mine[bounds[i] + s]] = annexb(i, s)
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, local_streams)   # host-side concatenation of NAL units, not a data-path collective
+            allg = {}
+            for g_ in gathered:
+                allg.update(g_)
+        else:
+            allg = local_streams
+        if rank == 0:
+            merged = pkg.merge_gop_streams([allg[g] for g in range(cfg["ngops"])])
+            check["rbsp_sha256"] = hashlib.sha256(merged).hexdigest()
+            check["expected"] = gold.get("bench_4k_64f_qp28_w32", {}).get("stream_sha256")
+            check["bytes"] = len(merged)
+    elif rank == 0 and args.content == "textured":
+        s0 = annexb(0, 0)
+        check["rbsp_sha256"] = hashlib.sha256(s0).hexdigest()
+        check["expected"] = gold.get("bench_1080p_30f_qp12_w32", {}).get("stream_sha256")
+        check["bytes"] = len(s0)
+    if check["expected"] is not None:
+        check["ok"] = check["rbsp_sha256"] == check["expected"]
+        if not check["ok"]:
+            raise SystemExit(f"output hash mismatch: {check}")
+    del host_rbsp, host_len
+
+    # ---- PCIe-inclusive rate: pinned host pictures in (asynchronous, double-buffered upload), host RBSP out
+    value_e2e = None
+    if args.e2e and world == 1 and args.config == "1080p":
+        pinned = [p.cpu().pin_memory() for p in parts]
+        out_h = [torch.empty((2, encs[i].S, cap), dtype=torch.uint8).pin_memory() for i in range(NC)]
+        len_h = [torch.zeros((2, encs[i].S), dtype=torch.int32).pin_memory() for i in range(NC)]
+
+        def e2e_ctx(i):
+            e, pin = encs[i], pinned[i]
+            e.upload_frames(pin[0].data_ptr())
+            for t in range(GOP):
+                if t + 1 < GOP:
+                    e.upload_frames(pin[t + 1].data_ptr())
+                e.set_frames_uploaded()
+                e.encode_picture_device(None)
+                e.copy_rbsp_host(out_h[i][t & 1], len_h[i][t & 1], cap)
+            e.sync()
+
+        threaded(e2e_ctx)   # warm-up (allocates the staging buffers)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        threaded(e2e_ctx)
+        torch.cuda.synchronize()
+        value_e2e = S * GOP * nmb / (time.perf_counter() - t1)
+        del pinned, out_h, len_h
+
+    # ---- roofline of the dominant kernel (by accumulated device time; every profiled phase is one kernel, except
     # "sort" = the six launches of the two radix passes and "cavlc" = size + scan + emit)
-    p_pictures = (GOP - 1) * args.steps
-    KERNELS = {  # phase -> (kernel, algorithmic bytes per macroblock, pictures it runs on)
-        "interp": ("k_interp", 256 + 16 * 256, p_pictures),
-        "features": ("k_features", 16 * 256 + 256 * (192 + 12), p_pictures),
-        "sort_keys": ("k_sort_keys", 256 * (2 + 8), p_pictures),
-        "sort": ("k_rs_hist+k_rs_scan+k_rs_scatter (two radix passes)", 2 * 256 * (4 + 8 + 8), p_pictures),
-        "sort_finish": ("k_sort_finish", 256 * (8 + 12 + 16), p_pictures),
-        "me_pre": ("k_me_pre", ME_BYTES_PER_MB, p_pictures),
-        "me_walk": ("k_me_walk", ME_BYTES_PER_MB, p_pictures),
-        "me_resolve": ("k_me_resolve", ME_BYTES_PER_MB, p_pictures),
-        "p_resid": ("k_p_resid", 1152, p_pictures),
-        "intra": ("k_intra_mb", 768, args.steps),
-        "cavlc": ("k_cavlc", 800, GOP * args.steps),
-    }
-    # HBM traffic per macroblock from the committed PMC measurement (profiles/r01_traffic.json); None when absent
+    pics = {"P": (GOP - 1) * args.steps, "I": args.steps, "all": GOP * args.steps}
     per_mb_traffic = {}
-    tj = ROOT / "profiles" / "r01_traffic.json"
-    if tj.exists():
-        per_mb_traffic = json.loads(tj.read_text()).get("bytes_per_mb", {})
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        tj = ROOT / "profiles" / name
+        if tj.exists():
+            per_mb_traffic = json.loads(tj.read_text()).get("bytes_per_mb", {})
+            break
 
     def line(k):
-        name, bpm, pics = KERNELS[k]
-        ms_, launches_ = prof[k]
-        units = S * nmb * pics  # accumulated over contexts, like ms_ and launches_
+        name, bpm, limiter, on = KERNELS[k]
+        ms_, launches_ = prof.get(k, (0.0, 0))
+        units = S * nmb * pics[on]  # accumulated over contexts, like ms_ and launches_
         per_launch_s = (ms_ / 1e3) / max(launches_, 1)
         ach = (bpm * units / max(launches_, 1)) / per_launch_s / 1e9 if ms_ > 0 else 0.0
         tr = per_mb_traffic.get(k)
-        return {"kernel": name, "achieved": round(ach, 3), "frac": round(ach / HBM_PEAK_GBS, 6),
+        return {"kernel": name, "limiter": limiter, "achieved": round(ach, 3), "frac": round(ach / HBM_PEAK_GBS, 6),
                 "traffic": round(tr * units / max(launches_, 1)) if tr else None,
                 "avg_launch_us": round(per_launch_s * 1e6, 2), "launches": launches_, "bytes_per_mb": bpm,
                 "total_ms": round(ms_, 2)}
 
-    dom = max(KERNELS, key=lambda k: prof[k][0])
+    live = [k for k in KERNELS if prof.get(k, (0.0, 0))[0] > 0]
+    dom = max(live, key=lambda k: prof[k][0])
     dl = line(dom)
-    roofline = {"bound": "hbm", "kernel": dl["kernel"], "achieved": dl["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dl["frac"], "traffic": dl["traffic"], "avg_launch_us": dl["avg_launch_us"],
-                "launches": dl["launches"], "bytes_per_mb": dl["bytes_per_mb"],
-                "kernels": {k: line(k) for k in KERNELS}}
+    valu_frac = value * LANE_OPS_PER_MB / VALU_LANE_OPS / max(world, 1) if args.config == "1080p" else None
+    roofline = {"bound": "hbm", "kernel": dl["kernel"], "limiter": dl["limiter"], "achieved": dl["achieved"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dl["frac"], "traffic": dl["traffic"],
+                "avg_launch_us": dl["avg_launch_us"], "launches": dl["launches"], "bytes_per_mb": dl["bytes_per_mb"],
+                "valu_frac": round(valu_frac, 5) if valu_frac is not None else None,
+                "valu_note": "per-GPU macroblocks/s x 2.1e5 lane-ops per macroblock (reference-exact search, SURVEY 8d) / 78.6e12 lane-ops/s",
+                "kernels": {k: line(k) for k in live}}
 
     out = None
     if rank == 0:
-        cpu = None
+        cpu = cpu_n = None
         if world == 1 and args.cpu_frames > 0:
-            res = cpu_baseline(parts[0][:, 0].cpu().numpy(), args.cpu_frames)
+            sample = parts[0][:, 0].cpu().numpy()
+            p, tmp = run_oracle_enc(cfg, sample, args.cpu_frames, "one")
+            res = finish_oracle(p, tmp)
             cpu = {"value": round(res["mb_per_s"], 1), "unit": "macroblocks/s", "cores": 1, "kind": "port",
                    "sample": f"first {args.cpu_frames} pictures (I+{args.cpu_frames - 1}P) of stream 0, "
                              f"{res['mbs']} MBs in {res['seconds']:.1f} s, oracle/fo_cli single thread"}
+            # N independent processes over streams (the reference's only route to several cores): N = host cores
+            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            ncpu = max(1, min(ncpu, parts[0].shape[1] if NC == 1 else S, 64))
+            t2 = time.perf_counter()
+            jobs = [run_oracle_enc(cfg, parts[0][:, k % parts[0].shape[1]].cpu().numpy(), args.cpu_frames, f"n{k}")
+                    for k in range(ncpu)]
+            mbs = sum(finish_oracle(p_, t_)["mbs"] for p_, t_ in jobs)
+            wall = time.perf_counter() - t2
+            cpu_n = {"value": round(mbs / wall, 1), "unit": "macroblocks/s", "cores": ncpu, "kind": "port",
+                     "sample": f"{ncpu} fo_cli processes, {args.cpu_frames} pictures of one stream each, wall {wall:.1f} s "
+                               "(input written to disk inside the timed region)"}
+        secondary = None
+        if world == 1 and args.secondary and args.config == "1080p":
+            for e in encs:
+                e.close()
+            encs.clear()
+            secondary = run_secondary(pkg, torch, dev)
+        coded = int(counts.sum())
         out = {"metric": "macroblocks/sec encode (1080p full-search ME) + bit-exact bitstream vs ref",
                "value": round(value, 1), "unit": "macroblocks/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-               "config": {"workload": "1080p IPPP encode, full-search +-16 ME (BASELINE configs[2])",
-                          "coded_size": f"{W}x{H}", "streams_per_gpu": S, "contexts_per_gpu": NC, "gop": GOP, "qp": QP, "window": WINDOW,
-                          "maxdiff": MAXDIFF, "mbs_per_step": world * S * GOP * nmb,
+               "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": cfg["workload"], "content": args.content,
+                          "coded_size": f"{W}x{H}", "streams_per_gpu": S, "contexts_per_gpu": NC, "gop": GOP, "qp": cfg["qp"],
+                          "window": cfg["window"], "maxdiff": cfg["maxdiff"], "mbs_per_step": total_streams * GOP * nmb,
                           "parallelism": f"{world} x {S} independent closed-GOP streams"},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_nproc": cpu_n,
+               "value_e2e": round(value_e2e, 1) if value_e2e else None,
+               "value_e2e_note": "pinned host pictures in (double-buffered asynchronous H2D), host RBSP out (D2H), same streams and GOP",
+               "skip_fraction": round(float(counts[0]) / coded, 6) if coded else None,
+               "mb_types": {"p_skip": int(counts[0]), "p16x16": int(counts[1]), "p16x8": int(counts[2]),
+                            "p8x16": int(counts[3]), "p8x8": int(counts[4])},
+               "output_check": check, "secondary": secondary}
         print(json.dumps(out), flush=True)
     for e in encs:
         e.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_secondary(pkg, torch, dev):
+    """BASELINE configs[1] (720p I-only, many pictures in flight) and configs[4] (1080p decode), short runs."""
+    import numpy as np
+    from h264_fer_amd.synth import gen_frames_torch
+    res = {}
+    # ---- 720p I-frame encode: S streams x T pictures, IntraEvery 1
+    W, H, S, T = 1280, 720, 256, 4
+    fr = gen_frames_torch(W, H, 1, S, dev, seed=77, noise=2)[0].contiguous()
+    e = pkg.FerHip(W, H, S, qp=12, window=16, maxdiff=3, intra_every=1)
+    for _ in range(1):
+        e.set_frames_device(fr.data_ptr())
+        e.encode_picture_device(None)
+    e.sync()
+    t0 = time.perf_counter()
+    for _ in range(T):
+        e.set_frames_device(fr.data_ptr())
+        e.encode_picture_device(None)
+    e.sync()
+    dt = time.perf_counter() - t0
+    ok = not any(e.status())
+    res["720p_intra"] = {"workload": "720p I-frame encode (BASELINE configs[1])", "value": round(S * T * e.nmb / dt, 1),
+                         "unit": "macroblocks/s", "streams": S, "pictures": T, "qp": 12, "status_ok": ok}
+    e.close()
+    del fr
+    # ---- 1080p decode of the encoder's own IPPP output (host Annex-B in, pictures left in HBM)
+    W, H, S, T = 1920, 1072, 16, 8
+    fr = gen_frames_torch(W, H, T, S, dev, seed=1234, noise=2).cpu().numpy()
+    e = pkg.FerHip(W, H, S, qp=12, window=32, maxdiff=3, intra_every=30)
+    streams, _ = e.encode_streams(fr)
+    nmb = e.nmb
+    e.close()
+    reps = 4
+    batch = streams * reps
+    pkg.decode_streams(batch, T, want_pictures=False)   # first call allocates the window arena
+    t0 = time.perf_counter()
+    _, pics, _, _ = pkg.decode_streams(batch, T, want_pictures=False)
+    dt = time.perf_counter() - t0
+    res["1080p_decode"] = {"workload": "1080p decode (CAVLC parse + dequant + inverse 4x4), BASELINE configs[4]",
+                           "value": round(len(batch) * T * nmb / dt, 1), "unit": "macroblocks/s", "streams": len(batch),
+                           "pictures": T, "all_decoded": pics == [T] * len(batch)}
+    pkg.load_library().ferhip_decode_release()
+    return res
 
 
 if __name__ == "__main__":

@@ -48,6 +48,11 @@ struct ferhip_ctx {
     unsigned long long *h_sad;
     std::vector<int> types;
     uint8_t *planes[2];    // two picture sets, swapped after every picture
+    // asynchronous ingest (ferhip_upload_frames): pinned host pictures -> stage[k] on a copy stream, double buffered
+    hipStream_t st_copy;
+    uint8_t *stage[2];
+    hipEvent_t up_done[2], up_used[2];
+    int up_next, up_ready;  // slot the next upload fills; uploads waiting to be made current
     int cur_set;
     bool refprep_valid;
     // live kernel timing with HIP events on the launch stream (bench.py roofline leg)
@@ -107,7 +112,35 @@ static void bind_planes(ferhip_ctx *c)
     (void)fsz;
 }
 
-extern "C" const char *ferhip_version(void) { return "ferhip 0.1 (gfx950)"; }
+extern "C" const char *ferhip_version(void) { return "ferhip 0.2 (gfx950)"; }
+
+// ---- device / pinned memory for hosts without a HIP binding of their own (cgo, JNI, ctypes ...): the pictures of
+// ferhip_set_frames(host = 0), the buffers of ferhip_copy_rbsp and the pinned sources of ferhip_upload_frames
+extern "C" void *ferhip_mem_alloc(size_t bytes, int kind)  // kind 0 = device (HBM), 1 = pinned host
+{
+    void *p = nullptr;
+    hipError_t e = kind ? hipHostMalloc(&p, bytes) : hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void ferhip_mem_free(void *p, int kind)
+{
+    if (!p) return;
+    if (kind)
+        hipHostFree(p);
+    else
+        hipFree(p);
+}
+// synchronous copy between host and device memory (direction inferred by the runtime)
+extern "C" int ferhip_mem_copy(void *dst, const void *src, size_t bytes)
+{
+    if (!dst || !src) return FERHIP_E_ARG;
+    CK(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+    return 0;
+}
 
 static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params *p, bool decode_only);
 extern "C" int ferhip_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params *p)
@@ -133,6 +166,10 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     c->h_sad = nullptr;
     for (int i = 0; i < FER_HDR_SLOTS; i++) c->hdr_ev[i] = nullptr;
     c->planes[0] = c->planes[1] = nullptr;
+    c->st_copy = nullptr;
+    c->stage[0] = c->stage[1] = nullptr;
+    c->up_done[0] = c->up_done[1] = c->up_used[0] = c->up_used[1] = nullptr;
+    c->up_next = c->up_ready = 0;
     c->p = *p;
     FerDev &d = c->d;
     d.W = W;
@@ -148,7 +185,11 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     d.window = p->window;
     d.maxdiff_set = p->maxdiff;
     d.basic = p->basic ? 1 : 0;
+#ifdef FER_PROBE
     d.dbg = getenv("FER_DBG") ? atoi(getenv("FER_DBG")) : 0;
+#else
+    d.dbg = 0;  // no environment variable changes what the shipped library computes
+#endif
     d.ysz = (size_t)W * H;
     d.csz = d.ysz / 4;
     {
@@ -264,6 +305,14 @@ extern "C" void ferhip_destroy(ferhip_ctx *c)
     if (c->h_len) hipHostFree(c->h_len);
     if (c->h_status) hipHostFree(c->h_status);
     if (c->h_sad) hipHostFree(c->h_sad);
+    if (c->st_copy) {
+        hipStreamSynchronize(c->st_copy);
+        hipStreamDestroy(c->st_copy);
+    }
+    for (int i = 0; i < 2; i++) {
+        if (c->up_done[i]) hipEventDestroy(c->up_done[i]);
+        if (c->up_used[i]) hipEventDestroy(c->up_used[i]);
+    }
     if (c->st) hipStreamDestroy(c->st);
     if (c->st_hi) hipStreamDestroy(c->st_hi);
     if (c->ev_a) hipEventDestroy(c->ev_a);
@@ -330,6 +379,50 @@ extern "C" int ferhip_set_frames(ferhip_ctx *c, const void *src, int host)
                          host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice);
     if (rc) return rc;
     if (host) CK(hipStreamSynchronize(c->st));
+    return 0;
+}
+
+// ---- asynchronous ingest: ReadFromY4M's successor for many streams (row f3) ----
+// ferhip_upload_frames starts the H2D copy of the NEXT pictures ([S][W*H*3/2], pinned host memory) on a copy stream
+// of its own and returns; up to two uploads may be in flight.  ferhip_set_frames_uploaded makes the oldest one the
+// current picture (the repack runs on the encode stream behind the copy).  So the upload of picture t + 1 overlaps
+// the encode of picture t.
+extern "C" int ferhip_upload_frames(ferhip_ctx *c, const void *pinned_src)
+{
+    if (!c || !pinned_src) return FERHIP_E_ARG;
+    (void)hipSetDevice(c->device);
+    FerDev &d = c->d;
+    const size_t bytes = d.ysz * 3 / 2 * d.S;
+    if (!c->st_copy) {
+        CK(hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            CK(dalloc(c, &c->stage[i], bytes) ? hipErrorOutOfMemory : hipSuccess);
+            CK(hipEventCreateWithFlags(&c->up_done[i], hipEventDisableTiming));
+            CK(hipEventCreateWithFlags(&c->up_used[i], hipEventDisableTiming));
+        }
+        CK(hipDeviceSynchronize());  // dalloc clears on the null stream
+    }
+    if (c->up_ready >= 2) return FERHIP_E_STATE;
+    const int k = c->up_next;
+    CK(hipStreamWaitEvent(c->st_copy, c->up_used[k], 0));  // the repack that last read this slot
+    CK(hipMemcpyAsync(c->stage[k], pinned_src, bytes, hipMemcpyHostToDevice, c->st_copy));
+    CK(hipEventRecord(c->up_done[k], c->st_copy));
+    c->up_next ^= 1;
+    c->up_ready++;
+    return 0;
+}
+
+extern "C" int ferhip_set_frames_uploaded(ferhip_ctx *c)
+{
+    if (!c) return FERHIP_E_ARG;
+    if (c->up_ready <= 0) return FERHIP_E_STATE;
+    (void)hipSetDevice(c->device);
+    const int k = (c->up_next + 2 - c->up_ready) & 1;  // oldest upload in flight
+    CK(hipStreamWaitEvent(c->st, c->up_done[k], 0));
+    int rc = copy_frames(c, c->planes[c->cur_set], c->stage[k], nullptr, hipMemcpyDeviceToDevice);
+    if (rc) return rc;
+    CK(hipEventRecord(c->up_used[k], c->st));
+    c->up_ready--;
     return 0;
 }
 
@@ -637,7 +730,7 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
             CK(hipEventRecord(c->ev_a, c->st));
             CK(hipStreamWaitEvent(c->st_hi, c->ev_a, 0));
             {
-                ProfScope ps(c, FERHIP_PH_ME_RESOLVE, fer_me_resolve_launches(d), c->st_hi);
+                ProfScope ps(c, FERHIP_PH_ME_RESOLVE, 1, c->st_hi);
                 d.serial = d.serial % 0x7ffffff0 + 1;  // validates this picture's words in chain64
                 fer_launch_me_resolve(d, c->st_hi);
             }
@@ -878,7 +971,7 @@ extern "C" int ferhip_inter_encoding(ferhip_ctx *c)
         fer_launch_me_walk(c->d, c->st);
     }
     {
-        ProfScope ps(c, FERHIP_PH_ME_RESOLVE, fer_me_resolve_launches(c->d));
+        ProfScope ps(c, FERHIP_PH_ME_RESOLVE, 1);
         c->d.serial = c->d.serial % 0x7ffffff0 + 1;
         fer_launch_me_resolve(c->d, c->st);
     }
@@ -1594,42 +1687,77 @@ extern "C" int ferhip_dec_nal(ferhip_dec *dc, int nal_unit_type, int nal_ref_idc
     return 0;
 }
 
-// ---- block-level KATs: forwardResidual / inverseResidual on the device
-__global__ void k_block_kat(int qP, const int32_t *in, int32_t *out, int keep_dc, int inverse, size_t n)
+// ---- block-level KATs: the reference's per-block entry points (F/quantizationTransform.h, F/scaleTransform.h) as
+// batched device calls over the SAME device functions the production kernels use (fer_dev.h)
+#define KAT_FWD_RESIDUAL 0
+#define KAT_INV_RESIDUAL 1
+#define KAT_FWD_DC_LUMA 2
+#define KAT_INV_DC_LUMA 3
+#define KAT_FWD_DC_CHROMA 4
+#define KAT_INV_DC_CHROMA 5
+#define KAT_SCAN 6
+#define KAT_INV_SCAN 7
+__global__ void k_block_kat(int op, int qP, const int32_t *in, int32_t *out, int flag, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int a[16], t[16], b[16];
-    for (int k = 0; k < 16; k++) a[k] = in[i * 16 + k];
-    if (inverse) {
-        inv4x4(a, b, qP, keep_dc != 0);
-    } else {
+    for (int k = 0; k < 16; k++) {
+        a[k] = in[i * 16 + k];
+        b[k] = 0;
+    }
+    switch (op) {
+    case KAT_FWD_RESIDUAL:
         fwd4x4(a, t);
-        quant4x4(t, b, qP, keep_dc != 0);
+        quant4x4(t, b, qP, flag != 0);
+        break;
+    case KAT_INV_RESIDUAL: inv4x4(a, b, qP, flag != 0); break;
+    case KAT_FWD_DC_LUMA: fwd_dc_luma(a, b, qP); break;
+    case KAT_INV_DC_LUMA: inv_dc_luma(a, b, qP); break;
+    case KAT_FWD_DC_CHROMA: fwd_dc_chroma(a, b, qP); break;   // 2x2 raster in slots 0..3
+    case KAT_INV_DC_CHROMA: inv_dc_chroma(a, b, qP); break;
+    case KAT_SCAN:  // transformScan: flag = Intra16x16AC (15 entries from index 1)
+        for (int k = flag ? 1 : 0; k < 16; k++) b[k - (flag ? 1 : 0)] = a[c_zz[k]];
+        break;
+    default:  // transformInverseScan
+        for (int k = 0; k < 16; k++) b[c_zz[k]] = a[k];
+        break;
     }
     for (int k = 0; k < 16; k++) out[i * 16 + k] = b[k];
 }
 
-static int block_kat(int qP, const int32_t *in, int32_t *out, int keep_dc, int inverse, size_t n)
+static int block_kat(int op, int qP, const int32_t *in, int32_t *out, int flag, size_t n)
 {
     if (!in || !out || qP < 0 || qP > 51) return FERHIP_E_ARG;
+    if (n == 0) return 0;
     int32_t *di = nullptr, *dout = nullptr;
     CK(hipMalloc((void **)&di, n * 64));
-    CK(hipMalloc((void **)&dout, n * 64));
-    CK(hipMemcpy(di, in, n * 64, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_block_kat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, qP, di, dout, keep_dc, inverse, n);
-    CK(hipGetLastError());
-    CK(hipMemcpy(out, dout, n * 64, hipMemcpyDeviceToHost));
+    if (hipMalloc((void **)&dout, n * 64) != hipSuccess) {
+        hipFree(di);
+        return FERHIP_E_HIP;
+    }
+    int rc = 0;
+    if (hipMemcpy(di, in, n * 64, hipMemcpyHostToDevice) != hipSuccess) rc = FERHIP_E_HIP;
+    if (!rc) {
+        hipLaunchKernelGGL(k_block_kat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, qP, di, dout, flag, n);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out, dout, n * 64, hipMemcpyDeviceToHost) != hipSuccess) rc = FERHIP_E_HIP;
+    }
     hipFree(di);
     hipFree(dout);
-    return 0;
+    return rc;
 }
 
 extern "C" int ferhip_forward_residual(int qP, const int32_t *in, int32_t *out, int keep_dc, size_t n)
 {
-    return block_kat(qP, in, out, keep_dc, 0, n);
+    return block_kat(KAT_FWD_RESIDUAL, qP, in, out, keep_dc, n);
 }
 extern "C" int ferhip_inverse_residual(int qP, const int32_t *in, int32_t *out, int keep_dc, size_t n)
 {
-    return block_kat(qP, in, out, keep_dc, 1, n);
+    return block_kat(KAT_INV_RESIDUAL, qP, in, out, keep_dc, n);
 }
+extern "C" int ferhip_forward_dc_luma_intra(int qP, const int32_t *in, int32_t *out, size_t n) { return block_kat(KAT_FWD_DC_LUMA, qP, in, out, 0, n); }
+extern "C" int ferhip_inverse_dc_luma_intra(int qP, const int32_t *in, int32_t *out, size_t n) { return block_kat(KAT_INV_DC_LUMA, qP, in, out, 0, n); }
+extern "C" int ferhip_forward_dc_chroma(int qP, const int32_t *in, int32_t *out, size_t n) { return block_kat(KAT_FWD_DC_CHROMA, qP, in, out, 0, n); }
+extern "C" int ferhip_inverse_dc_chroma(int qP, const int32_t *in, int32_t *out, size_t n) { return block_kat(KAT_INV_DC_CHROMA, qP, in, out, 0, n); }
+extern "C" int ferhip_transform_scan(const int32_t *in, int32_t *out, int intra16x16_ac, size_t n) { return block_kat(KAT_SCAN, 0, in, out, intra16x16_ac, n); }
+extern "C" int ferhip_transform_inverse_scan(const int32_t *in, int32_t *out, size_t n) { return block_kat(KAT_INV_SCAN, 0, in, out, 0, n); }

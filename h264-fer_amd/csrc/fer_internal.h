@@ -22,7 +22,6 @@ void fer_launch_frame_sad(const FerDev &d, hipStream_t st);
 void fer_launch_me_pre(const FerDev &d, hipStream_t st);
 void fer_launch_me_resolve(const FerDev &d, hipStream_t st);
 void fer_launch_basic_stat(const FerDev &d, hipStream_t st);
-int fer_me_resolve_launches(const FerDev &d);
 void fer_launch_p_resid(const FerDev &d, hipStream_t st);
 void fer_launch_intra(const FerDev &d, hipStream_t st);
 void fer_launch_cavlc(const FerDev &d, hipStream_t st);

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
 
 #ifdef FER_PROBE
-    const bool probe = (d.dbg & 128) && s == 0 && (blockIdx.x % 997) == 5;  // a sample of partitions reports its time split
+    const bool probe = FER_DBGF(d, 128) && s == 0 && (blockIdx.x % 997) == 5;  // a sample of partitions reports its time split
     long long tmark = probe ? wall_clock64() : 0;
 #define PP_MARK(k)                                                          \
     if (probe) {                                                            \
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     const int r2 = window / 16, n2w = 2 * r2 + 1, nloc = n2w * n2w * 16;
     const uint16_t *F0 = d.feat0 + (size_t)s * 6 * ysz;
     const int wb = (n * n + 63) >> 6;  // batches of the wide search
-    if (n * n <= ME_WIDE_LDS && wb + ((nloc + 63) >> 6) <= ME_SEL_NB && !(d.dbg & 3)) {
+    if (n * n <= ME_WIDE_LDS && wb + ((nloc + 63) >> 6) <= ME_SEL_NB && !FER_DBGF(d, 3)) {
         // pass A: lanes run along x (contiguous 12-byte records); metrics land in LDS at their
         // arrival index (tx outer, ty inner).  Records are fetched six batches at a time with
         // clamped coordinates (no control flow around the loads), then masked.
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
         select_topk<ME_SEL_NB>(v, 33, lane, sel_lds, L, raw, fin);
         PP_MARK(3)
     } else {
-        for (int base = 0; base < n * n && !(d.dbg & 1); base += 64) {
+        for (int base = 0; base < n * n && !FER_DBGF(d, 1); base += 64) {
             int c = base + lane;
             int tx = c / n - R, ty = c % n - R;
             int rx = sx + tx, ry = sy + ty;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
             if (ok) m = (iabs(tx) + iabs(ty) + 4) * feat_dist_rec(F0 + ((size_t)ry * W + rx) * 6, sp);
             wl_insert(L, 33, lane, ok, m, pack_xy(tx * 4, ty * 4));
         }
-        for (int base = 0; base < nloc && !(d.dbg & 2); base += 64) {
+        for (int base = 0; base < nloc && !FER_DBGF(d, 2); base += 64) {
             int c = base + lane;
             int frac = c & 15, pos = c >> 4;
             int tx = pos / n2w - r2, ty = pos % n2w - r2;
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
         }
     }
     const int n3 = __popcll(__ballot(lane < 33 && L.m < 100000000));
-    if (!(d.dbg & 4)) {  // SADs of the survivors: all five rounds' rows requested before the first reduction
+    if (!FER_DBGF(d, 4)) {  // SADs of the survivors: all five rounds' rows requested before the first reduction
         SadRow rr[5];
         int xyr[5];
 #pragma unroll
@@ -567,7 +567,7 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
                                             SINK sink)
 {
     int tren = 0;
-    if (d.basic || (d.dbg & 8)) return 0;
+    if (d.basic || FER_DBGF(d, 8)) return 0;
     const int kt = d.kt;
     const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * kt;
     const uint32_t *srec = d.sort_rec;  // indexed by the device-wide positions kol2 holds
@@ -812,7 +812,7 @@ __device__ __forceinline__ void res_prefetch(const FerDev &d, int s, int gx, int
     if (role == 1 && !d.basic) {
         p.n2raw = d.st2n[pidx];
         p.n2 = min(p.n2raw, FER_ST2_CAP);
-        p.n3 = (d.dbg & 64) ? 0 : d.st3n[pidx];
+        p.n3 = FER_DBGF(d, 64) ? 0 : d.st3n[pidx];
         const int2 *c2 = (const int2 *)(d.st2 + pidx * FER_ST2_CAP * 2);
 #pragma unroll
         for (int u = 0; u < FER_ST2_CAP / 64; u++) p.e2[u] = c2[u * 64 + lane];  // slots >= n2 hold stale data, masked later
@@ -934,7 +934,7 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
     WList L1;
     L1.m = INF_M;
     L1.xy = 0;
-    const int r1 = window / 16, n1 = 2 * r1 + 1, tot1 = (d.dbg & 16) ? 0 : n1 * n1 * 16;
+    const int r1 = window / 16, n1 = 2 * r1 + 1, tot1 = FER_DBGF(d, 16) ? 0 : n1 * n1 * 16;
     auto raw1 = [&](int u) { return u * 64 + lane; };  // arrival index
     auto fin1 = [&](int cc) {
         int frac = cc & 15, pos = cc >> 4;
@@ -991,7 +991,7 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
     const int sx = gx * 8, sy = gy * 8;
     k2 = k3 = 0x7fffffff;
     xy2 = xy3 = 0;
-    if (d.basic || (d.dbg & 32)) return;
+    if (d.basic || FER_DBGF(d, 32)) return;
     int mvpx, mvpy;
     predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
     const int genx = mvpx >> 2, geny = mvpy >> 2;
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
     const unsigned serial = (unsigned)d.serial & 0x7fffffffu;
 
 #ifdef FER_PROBE
-    const bool probe = (d.dbg & 128) && s == 0 && gy == gh / 2;  // one row reports where its time goes
+    const bool probe = FER_DBGF(d, 128) && s == 0 && gy == gh / 2;  // one row reports where its time goes
 #define PR_MARK(k)                        \
     if (probe) {                          \
         long long now_ = wall_clock64();  \
@@ -1297,17 +1297,15 @@ void fer_launch_me_walk(const FerDev &d, hipStream_t st)
     hipLaunchKernelGGL(k_me_walk, dim3(d.nmb * 4, d.S), dim3(64), 0, st, d);
 }
 
-int fer_me_resolve_launches(const FerDev &d)
-{
-    (void)d;
-    return 1;
-}
-
 void fer_launch_me_resolve(const FerDev &d, hipStream_t st)
 {
     const int gh = 2 * d.mbh;
     hipMemsetAsync(d.chain, 0, sizeof(int), st);
+#ifdef FER_PROBE
     static const int cap = getenv("FER_RESOLVE_WGS") ? atoi(getenv("FER_RESOLVE_WGS")) : 1536;
+#else
+    const int cap = 1536;
+#endif
     dim3 g(min(gh * d.S, max(cap, 1)));
     if (d.window == 32)
         hipLaunchKernelGGL(k_me_resolve<32>, g, dim3(128), 0, st, d);

@@ -44,7 +44,14 @@ def load_library():
     lib.ferhip_destroy.argtypes = [vp]
     lib.ferhip_destroy.restype = None
     lib.ferhip_set_frames.argtypes = [vp, vp, i]
+    lib.ferhip_mem_alloc.argtypes = [sz, i]
+    lib.ferhip_mem_alloc.restype = vp
+    lib.ferhip_mem_free.argtypes = [vp, i]
+    lib.ferhip_mem_free.restype = None
+    lib.ferhip_mem_copy.argtypes = [vp, vp, sz]
     lib.ferhip_set_reference.argtypes = [vp, vp]
+    lib.ferhip_upload_frames.argtypes = [vp, vp]
+    lib.ferhip_set_frames_uploaded.argtypes = [vp]
     lib.ferhip_encode_picture.argtypes = [vp, C.POINTER(i), vp, sz, C.POINTER(C.c_uint32)]
     lib.ferhip_encode_picture_dev.argtypes = [vp, C.POINTER(i), C.POINTER(vp), C.POINTER(sz), C.POINTER(vp)]
     lib.ferhip_select_nal_type.argtypes = [vp, C.POINTER(i)]
@@ -80,6 +87,10 @@ def load_library():
     lib.ferhip_y4m_write_frame.argtypes = [vp, vp, i, i, i]
     lib.ferhip_forward_residual.argtypes = [i, vp, vp, i, sz]
     lib.ferhip_inverse_residual.argtypes = [i, vp, vp, i, sz]
+    for n_ in ("forward_dc_luma_intra", "inverse_dc_luma_intra", "forward_dc_chroma", "inverse_dc_chroma"):
+        getattr(lib, "ferhip_" + n_).argtypes = [i, vp, vp, sz]
+    lib.ferhip_transform_scan.argtypes = [vp, vp, i, sz]
+    lib.ferhip_transform_inverse_scan.argtypes = [vp, vp, sz]
     _lib = lib
     return lib
 
@@ -87,6 +98,37 @@ def load_library():
 def _chk(rc, what):
     if rc != 0:
         raise FerHipError(f"{what} failed with code {rc}")
+
+
+class DeviceBuffer:
+    """HBM (or pinned host) memory through the library's own runtime (ferhip_mem_*), for callers without torch."""
+
+    def __init__(self, nbytes, pinned=False):
+        self.lib = load_library()
+        self.nbytes, self.kind = nbytes, int(pinned)
+        self.ptr = self.lib.ferhip_mem_alloc(nbytes, self.kind)
+        if not self.ptr:
+            raise FerHipError(f"ferhip_mem_alloc({nbytes}) failed")
+
+    def upload(self, arr, offset=0):
+        a = np.ascontiguousarray(arr)
+        _chk(self.lib.ferhip_mem_copy(C.c_void_p(self.ptr + offset), a.ctypes.data, a.nbytes), "ferhip_mem_copy")
+
+    def download(self, nbytes=None, offset=0, dtype=np.uint8):
+        out = np.empty((nbytes or self.nbytes) // np.dtype(dtype).itemsize, dtype)
+        _chk(self.lib.ferhip_mem_copy(out.ctypes.data, C.c_void_p(self.ptr + offset), out.nbytes), "ferhip_mem_copy")
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.lib.ferhip_mem_free(C.c_void_p(self.ptr), self.kind)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class FerHip:
@@ -122,6 +164,13 @@ class FerHip:
 
     def set_frames_device(self, dptr):
         _chk(self.lib.ferhip_set_frames(self.ctx, C.c_void_p(int(dptr)), 0), "ferhip_set_frames(dev)")
+
+    def upload_frames(self, host_ptr):
+        """start the asynchronous H2D copy of the next pictures (pinned host memory, [S][fsz])"""
+        _chk(self.lib.ferhip_upload_frames(self.ctx, C.c_void_p(int(host_ptr))), "ferhip_upload_frames")
+
+    def set_frames_uploaded(self):
+        _chk(self.lib.ferhip_set_frames_uploaded(self.ctx), "ferhip_set_frames_uploaded")
 
     def set_reference(self, frames):
         a = np.ascontiguousarray(frames, dtype=np.uint8).reshape(self.S, self.fsz)
@@ -253,6 +302,24 @@ def inverse_residual(qp, blocks, keep_dc=False):
     out = np.empty_like(a)
     _chk(lib.ferhip_inverse_residual(qp, a.ctypes.data, out.ctypes.data, int(keep_dc), a.shape[0]),
          "ferhip_inverse_residual")
+    return out
+
+
+def block_op(name, blocks, qp=0, flag=None):
+    """The per-block entry points of F/quantizationTransform.h / F/scaleTransform.h on n 16-int32 records (device):
+    forward_dc_luma_intra, inverse_dc_luma_intra, forward_dc_chroma, inverse_dc_chroma, transform_scan,
+    transform_inverse_scan."""
+    lib = load_library()
+    a = np.ascontiguousarray(blocks, np.int32).reshape(-1, 16)
+    out = np.empty_like(a)
+    f = getattr(lib, "ferhip_" + name)
+    if name == "transform_scan":
+        rc = f(a.ctypes.data, out.ctypes.data, int(bool(flag)), a.shape[0])
+    elif name == "transform_inverse_scan":
+        rc = f(a.ctypes.data, out.ctypes.data, a.shape[0])
+    else:
+        rc = f(qp, a.ctypes.data, out.ctypes.data, a.shape[0])
+    _chk(rc, "ferhip_" + name)
     return out
 
 

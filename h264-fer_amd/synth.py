@@ -76,11 +76,12 @@ def crop_to_mb(frame, W, H):
     return np.concatenate([Y.ravel(), U.ravel(), V.ravel()]), Wc, Hc
 
 
-def gen_frames_torch(W, H, n, S, device, seed=1234, noise=2):
+def gen_frames_torch(W, H, n, S, device, seed=1234, noise=2, seeds=None, t0s=None):
     """Same pictures as gen_frame(), built with torch integer ops on `device`: [n][S][W*H*3/2] uint8.
 
-    Stream s uses seed + s.  int64 arithmetic wraps like uint64; the logical right shifts are
-    emulated with masks."""
+    Stream s uses seed + s (or seeds[s]) and starts at time t0s[s] (default 0): closed GOPs of ONE sequence are
+    streams with the same seed and t0 = first picture of the GOP.  int64 arithmetic wraps like uint64; the logical
+    right shifts are emulated with masks."""
     import torch
 
     A = 6364136223846793005
@@ -110,9 +111,11 @@ def gen_frames_torch(W, H, n, S, device, seed=1234, noise=2):
         return torch.where(m < p // 2, m, p - m)
 
     for s in range(S):
-        sd = seed + s
+        sd = seeds[s] if seeds is not None else seed + s
+        tb = t0s[s] if t0s is not None else 0
         tex = torch.from_numpy(_tex(sd)).to(device)
-        for t in range(n):
+        for tt in range(n):
+            t = tb + tt
             base = s64(sd ^ ((_G * (t + 1)) & _M))
             z = idx + base
             z = lcg(z)
@@ -123,7 +126,7 @@ def gen_frames_torch(W, H, n, S, device, seed=1234, noise=2):
             else:
                 nz = 0
             v = 40 + tri(x + 2 * t, 192) + tri(y + t, 128) + tex[(y + t) & 63, (x + 2 * t) & 63] + nz
-            out[t, s, :ys] = v.clamp(16, 235).to(torch.uint8).reshape(-1)
-            out[t, s, ys: ys + ys // 4] = (104 + tri(xc + t, 96) // 2).to(torch.uint8).reshape(-1)
-            out[t, s, ys + ys // 4:] = (104 + tri(yc + t, 96) // 2).to(torch.uint8).reshape(-1)
+            out[tt, s, :ys] = v.clamp(16, 235).to(torch.uint8).reshape(-1)
+            out[tt, s, ys: ys + ys // 4] = (104 + tri(xc + t, 96) // 2).to(torch.uint8).reshape(-1)
+            out[tt, s, ys + ys // 4:] = (104 + tri(yc + t, 96) // 2).to(torch.uint8).reshape(-1)
     return out

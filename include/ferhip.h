@@ -52,10 +52,24 @@ typedef struct {
 int ferhip_create(ferhip_ctx **out, int width, int height, int nstreams, const ferhip_params *p);
 void ferhip_destroy(ferhip_ctx *c);
 
+/* Device (kind 0) / pinned host (kind 1) memory and synchronous copies for hosts without a HIP binding of their
+ * own: device pictures for ferhip_set_frames(host = 0), buffers for ferhip_copy_rbsp, pinned sources for
+ * ferhip_upload_frames. */
+void *ferhip_mem_alloc(size_t bytes, int kind);
+void ferhip_mem_free(void *p, int kind);
+int ferhip_mem_copy(void *dst, const void *src, size_t bytes);
+
 /* ---- picture input: replaces ReadFromY4M() filling the global `frame` (F/fileIO.cpp:258) ----
  * I420 pictures of coded size, one per stream, stream-major: [nstreams][W*H*3/2].
  * host = 1: src is host memory (copied H2D); host = 0: src is a device pointer (D2D). */
 int ferhip_set_frames(ferhip_ctx *c, const void *src, int host);
+
+/* Asynchronous ingest for many streams (the successor of ReadFromY4M's one-picture read, row f3 of SURVEY.md 8f):
+ * ferhip_upload_frames starts the H2D copy of the NEXT pictures ([nstreams][W*H*3/2] in pinned host memory) on the
+ * context's copy stream and returns (two uploads may be in flight); ferhip_set_frames_uploaded makes the oldest
+ * upload the current picture.  Uploading picture t + 1 before encoding picture t overlaps PCIe with the kernels. */
+int ferhip_upload_frames(ferhip_ctx *c, const void *pinned_src);
+int ferhip_set_frames_uploaded(ferhip_ctx *c);
 
 /* ---- RBSP_encode for slice NAL units (F/rbsp_encoding.cpp:139-323) ----
  * nal_type[s]: FERHIP_NAL_IDR / FERHIP_NAL_SLICE / FERHIP_NAL_AUTO per stream on input, the
@@ -191,6 +205,18 @@ int ferhip_y4m_write_frame(void *file, const unsigned char *i420, int width, int
 int ferhip_forward_residual(int qP, const int32_t *in, int32_t *out, int keep_dc, size_t nblocks);
 /* inverseResidual(bitDepth, qP, c, r, intra16x16OrChroma), F/scaleTransform.h */
 int ferhip_inverse_residual(int qP, const int32_t *in, int32_t *out, int keep_dc, size_t nblocks);
+/* forwardDCLumaIntra(qP, dcY, c) (F/quantizationTransform.cpp:293) / InverseDCLumaIntra(bitDepth, qP, c, dcY)
+ * (F/scaleTransform.h): 16 int32 raster in, 16 out */
+int ferhip_forward_dc_luma_intra(int qP, const int32_t *in, int32_t *out, size_t nblocks);
+int ferhip_inverse_dc_luma_intra(int qP, const int32_t *in, int32_t *out, size_t nblocks);
+/* forwardDCChroma(qP, dcC, c, Intra) (F/quantizationTransform.cpp:303) / InverseDCChroma: the 2x2 block (raster) in
+ * slots 0..3 of a 16-int32 record, the rest ignored / zero */
+int ferhip_forward_dc_chroma(int qP, const int32_t *in, int32_t *out, size_t nblocks);
+int ferhip_inverse_dc_chroma(int qP, const int32_t *in, int32_t *out, size_t nblocks);
+/* transformScan(c, list, Intra16x16AC) (F/quantizationTransform.cpp:310; AC variant: 15 entries from index 1,
+ * = scanChroma) and transformInverseScan(list, c) (F/scaleTransform.cpp:454) */
+int ferhip_transform_scan(const int32_t *in, int32_t *out, int intra16x16_ac, size_t nblocks);
+int ferhip_transform_inverse_scan(const int32_t *in, int32_t *out, size_t nblocks);
 
 #ifdef __cplusplus
 }

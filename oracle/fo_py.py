@@ -47,6 +47,10 @@ def lib():
         L.fo_dbg_set_frame.argtypes = [vp, vp, vp, vp]
         L.fo_forwardResidual.argtypes = [i, vp, vp, i]
         L.fo_inverseResidual.argtypes = [i, vp, vp, i]
+        for n_ in ("fo_forwardDCLumaIntra", "fo_forwardDCChroma", "fo_inverseDCLumaIntra", "fo_inverseDCChroma"):
+            getattr(L, n_).argtypes = [i, vp, vp]
+        L.fo_scan.argtypes = [vp, vp, i]
+        L.fo_invscan.argtypes = [vp, vp]
         L.fo_cavlc_encode_block.restype = C.c_uint
         L.fo_cavlc_encode_block.argtypes = [vp, vp, i, i, vp]
         _lib = L
@@ -181,3 +185,28 @@ def decode_stream_md5(stream):
     a = np.frombuffer(stream, np.uint8)
     n = L.fo_decode_stream(a.ctypes.data, a.size, CB(cb), None, None)
     return n, frames, state
+
+
+def block_op(name, blocks, qp=0, flag=None):
+    """oracle twin of h264_fer_amd.ferhip.block_op (16-int32 records; chroma DC uses slots 0..3)"""
+    L = lib()
+    a = np.ascontiguousarray(blocks, np.int32).reshape(-1, 16)
+    out = np.zeros_like(a)
+    for k in range(a.shape[0]):
+        if name == "forward_dc_luma_intra":
+            L.fo_forwardDCLumaIntra(qp, a[k].ctypes.data, out[k].ctypes.data)
+        elif name == "inverse_dc_luma_intra":
+            L.fo_inverseDCLumaIntra(qp, a[k].ctypes.data, out[k].ctypes.data)
+        elif name == "forward_dc_chroma":
+            i4, o4 = a[k, :4].copy(), np.zeros(4, np.int32)
+            L.fo_forwardDCChroma(qp, i4.ctypes.data, o4.ctypes.data)
+            out[k, :4] = o4
+        elif name == "inverse_dc_chroma":
+            i4, o4 = a[k, :4].copy(), np.zeros(4, np.int32)
+            L.fo_inverseDCChroma(qp, i4.ctypes.data, o4.ctypes.data)
+            out[k, :4] = o4
+        elif name == "transform_scan":
+            L.fo_scan(a[k].ctypes.data, out[k].ctypes.data, int(bool(flag)))
+        else:
+            L.fo_invscan(a[k].ctypes.data, out[k].ctypes.data)
+    return out

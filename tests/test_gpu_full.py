@@ -232,14 +232,15 @@ def test_bad_arguments_are_rejected(pkg):
         pkg.FerHip(176, 144, 0)          # no streams
 
 
-@pytest.mark.parametrize("W,H,T,qp,window,noise", [(176, 144, 5, 12, 16, 2), (176, 144, 4, 28, 32, 0), (1920, 1072, 3, 12, 32, 2)])
+@pytest.mark.parametrize("W,H,T,qp,window,noise", [(176, 144, 5, 12, 16, 2), (176, 144, 4, 12, 32, 0), (1920, 1072, 3, 12, 32, 2)])
 def test_basic_inter_encoding_matches_oracle(pkg, fo, W, H, T, qp, window, noise):
     """BasicInterEncoding = 1 (F/moestimation.cpp:394-397,470): the exhaustive pass whose vectors the reference
     discards leaves only brojTipova behind; stages 2 and 3 of the feature search are skipped.  Bitstream,
     reconstruction and the counters (P_Skip counted twice, the discarded pass's own 16x16 / 8x8 verdicts) must be
     the oracle's."""
     S = 2
-    frames = np.stack([np.stack([pkg.gen_frame(W, H, t, 99 + s, noise) for s in range(S)]) for t in range(T)])
+    # noise 0 = still content: P_Skip macroblocks
+    frames = np.stack([np.stack([pkg.gen_frame(W, H, t if noise else 0, 99 + s, noise) for s in range(S)]) for t in range(T)])
     g = pkg.FerHip(W, H, S, qp=qp, window=window, maxdiff=3, intra_every=30, basic=1)
     streams, rec = g.encode_streams(frames, want_recon=True)
     assert g.status() == [0] * S
@@ -442,33 +443,37 @@ def test_device_path_with_explicit_types_back_to_back(pkg, fo):
     through the device-input / device-output path of two contexts driven from two threads (what bench.py times)
     against the oracle."""
     import threading
-    import torch
     W, H, T, S = 176, 144, 6, 2
     types = [pkg.ferhip.NAL_IDR if t % 3 == 0 else pkg.ferhip.NAL_SLICE for t in range(T)]
-    res = {}
+    res, errs = {}, []
 
     def run(k):
-        frames = np.stack([np.stack([pkg.gen_frame(W, H, t, 40 + 10 * k + s, 2) for s in range(S)]) for t in range(T)])
-        dev = torch.from_numpy(frames).cuda()
-        g = pkg.FerHip(W, H, S, qp=16, window=16, maxdiff=3, intra_every=1000)
-        stride = g.nmb * 1024 + 4096
-        keep = torch.empty((T, S, stride), dtype=torch.uint8, device="cuda")
-        lens = torch.empty((T, S), dtype=torch.int32, device="cuda")
-        st = torch.cuda.Stream()
-        for t in range(T):
-            g.set_frames_device(dev[t].data_ptr())
-            p, strd, pl, nt = g.encode_picture_device([types[t]] * S)
-            assert strd == stride and nt == [types[t]] * S
-            # the library's stream is not torch's: order the copies behind the picture with a full status read at the end
-            g.copy_rbsp_device(keep[t].data_ptr(), lens[t].data_ptr())
-        assert g.status() == [0] * S
-        res[k] = (frames, keep.cpu().numpy(), lens.cpu().numpy(), g)
+        try:
+            frames = np.stack([np.stack([pkg.gen_frame(W, H, t, 40 + 10 * k + s, 2) for s in range(S)]) for t in range(T)])
+            g = pkg.FerHip(W, H, S, qp=16, window=16, maxdiff=3, intra_every=1000)
+            fsz, stride = g.fsz, g.nmb * 1024 + 4096
+            dev = pkg.DeviceBuffer(T * S * fsz)
+            dev.upload(frames)
+            keep = pkg.DeviceBuffer(T * S * stride)
+            lens = pkg.DeviceBuffer(T * S * 4)
+            for t in range(T):
+                g.set_frames_device(dev.ptr + t * S * fsz)
+                p, strd, pl, nt = g.encode_picture_device([types[t]] * S)
+                assert strd == stride and nt == [types[t]] * S
+                g.copy_rbsp_device(keep.ptr + t * S * stride, lens.ptr + t * S * 4)   # on the library's stream, asynchronous
+            assert g.status() == [0] * S
+            res[k] = (frames, keep.download().reshape(T, S, stride), lens.download(dtype=np.uint32).reshape(T, S), g)
+            for b_ in (dev, keep, lens):
+                b_.free()
+        except BaseException as ex:  # noqa: BLE001
+            errs.append(ex)
 
     th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
     for x in th:
         x.start()
     for x in th:
         x.join()
+    assert not errs, errs
     for k in range(2):
         frames, keep, lens, g = res[k]
         sps, pps = g.sps_pps()
@@ -479,3 +484,35 @@ def test_device_path_with_explicit_types_back_to_back(pkg, fo):
             got = sps + pps + b"".join(g.write_nal(types[t], keep[t, s, : lens[t, s]].tobytes()) for t in range(T))
             assert got == ref, (k, s)
         g.close()
+
+
+def test_gop_shards_over_two_contexts_equal_one_continuous_run(pkg, fo):
+    """The multi-GPU partitioning on one GPU: 4 closed GOPs of one sequence, sharded round-robin (gops_of_rank) over
+    2 "ranks" = 2 encoder contexts driven by 2 host threads, every GOP encoded by libferhip as its own stream, NAL
+    units merged on the host in GOP order -- equal to ONE continuous oracle run over the 16 pictures."""
+    import threading
+    W, H, G, T = 352, 288, 4, 4
+    frames = np.stack([pkg.gen_frame(W, H, t, 17, 2) for t in range(G * T)])
+    world = 2
+    res = {}
+
+    def rank_main(rank):
+        mine = pkg.gops_of_rank(G, world, rank)
+        fr = np.stack([frames[g * T:(g + 1) * T] for g in mine], axis=1)     # [T][len(mine)][fsz]
+        g_ = pkg.FerHip(W, H, len(mine), qp=20, window=32, maxdiff=3, intra_every=T)
+        streams, _ = g_.encode_streams(fr)
+        assert g_.status() == [0] * len(mine)
+        g_.close()
+        for k, g in enumerate(mine):
+            res[g] = streams[k]
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    merged = pkg.merge_gop_streams([res[g] for g in range(G)])
+    o = fo.Oracle(W, H, qp=20, window=32, maxdiff=3, intra_every=T)
+    whole, _ = o.encode_stream(frames)
+    o.close()
+    assert merged == whole

@@ -90,3 +90,76 @@ def test_stream_bytes_match_oracle(pkg, fo, intra_every, qp, window, noise):
         for t in range(T):
             assert np.array_equal(rec[t, s], ref_rec[t]), f"recon stream {s} frame {t}"
         assert streams[s] == ref_bytes, f"bitstream stream {s}: {len(streams[s])} vs {len(ref_bytes)}"
+
+
+def test_dc_transform_and_scan_kats(pkg, fo):
+    """Rows a3 / a4 / a5 at block level through the C ABI: forwardDCLumaIntra, InverseDCLumaIntra, forwardDCChroma,
+    InverseDCChroma (F/quantizationTransform.cpp:105-178,227-282, F/scaleTransform.cpp:154-189,247-261,344-421),
+    transformScan (both variants) and transformInverseScan, against the oracle, every QP class."""
+    from h264_fer_amd.ferhip import block_op
+    rng = np.random.default_rng(11)
+    n = 384
+    dc = rng.integers(-4000, 4001, size=(n, 16), dtype=np.int32)     # DC terms of 16 forward-transformed blocks
+    dc[::9] = 0
+    lv = rng.integers(-300, 301, size=(n, 16), dtype=np.int32)
+    for qp in (0, 5, 10, 12, 17, 23, 24, 29, 35, 36, 41, 51):
+        for name, data in (("forward_dc_luma_intra", dc), ("inverse_dc_luma_intra", lv),
+                           ("forward_dc_chroma", dc), ("inverse_dc_chroma", lv)):
+            g = block_op(name, data, qp)
+            o = fo.block_op(name, data, qp)
+            if "chroma" in name:
+                g, o = g[:, :4], o[:, :4]
+            assert np.array_equal(g, o), (name, qp)
+    for ac in (False, True):
+        assert np.array_equal(block_op("transform_scan", lv, flag=ac), fo.block_op("transform_scan", lv, flag=ac)), ac
+    assert np.array_equal(block_op("transform_inverse_scan", lv), fo.block_op("transform_inverse_scan", lv))
+    # round trip: inverse scan of the scan is the identity
+    assert np.array_equal(block_op("transform_inverse_scan", block_op("transform_scan", lv)), lv)
+
+
+def test_randomised_configuration_sweep(pkg, fo):
+    """A bounded slice of tools/sweep.py inside the suite: 20 random configurations (sizes, qp, WindowSize incl. the
+    general path, MAXDIFF incl. adaptive and 0, IntraEvery, noise, still content = P_Skip heavy, flat / black boxes,
+    BasicInterEncoding) -- encoder bitstream + reconstruction + counters and the decoder against the oracle."""
+    import random
+    rng = random.Random(20261004)
+    for it in range(20):
+        W, H = rng.choice([(176, 144), (352, 288), (64, 48), (128, 96), (320, 240), (16, 32), (48, 16)])
+        cfg = dict(qp=rng.choice([10, 12, 16, 20, 24, 28, 30]), window=rng.choice([16, 32, 32, 32, 48]),
+                   maxdiff=rng.choice([3, 3, -1, 0, 6]), intra_every=rng.choice([30, 30, 3, 2]), basic=rng.choice([0, 0, 0, 1]))
+        T, S = rng.choice([3, 4, 5]), rng.choice([1, 2, 3])
+        noise = rng.choice([0, 1, 2, 4])
+        seeds = [rng.randrange(1, 10000) for _ in range(S)]
+        still = rng.random() < 0.25
+        frames = np.stack([np.stack([pkg.gen_frame(W, H, 0 if still else t, seeds[s], 0 if still else noise) for s in range(S)])
+                           for t in range(T)])
+        shape = rng.choice(["none", "none", "flat_box", "black_box", "black_rows"])
+        if shape != "none" and W >= 64 and H >= 48:
+            for t in range(T):
+                for s_ in range(S):
+                    y = frames[t, s_][: W * H].reshape(H, W)
+                    x0, y0 = rng.randrange(0, W // 2), rng.randrange(0, H // 2)
+                    if shape == "flat_box":
+                        y[y0: y0 + H // 3, x0: x0 + W // 2] = rng.choice([16, 128, 235])
+                    elif shape == "black_box":
+                        y[y0: y0 + H // 4, x0: x0 + W // 3] = 0
+                    else:
+                        y[: 8 * rng.randrange(2, 5)] = 0
+        tag = (it, W, H, T, S, cfg, noise, still, shape)
+        g = pkg.FerHip(W, H, S, **cfg)
+        streams, rec = g.encode_streams(frames, want_recon=True)
+        assert g.status() == [0] * S, tag
+        counts = g.stats()
+        g.close()
+        for s in range(S):
+            o = fo.Oracle(W, H, **cfg)
+            ref, rr = o.encode_stream(frames[:, s])
+            oc = o.stats()
+            o.close()
+            assert streams[s] == ref, tag
+            assert np.array_equal(rec[:, s], rr), tag
+            assert list(counts[s]) == list(oc), tag
+        out, pics, w, h = pkg.decode_streams(streams, T)
+        assert pics == [T] * S, tag
+        for s in range(S):
+            assert np.array_equal(out[:, s], np.stack(fo.decode_stream_md5(streams[s])[1])), tag
