@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=3, help="pictures of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--secondary", type=int, default=1, help="also time configs[1] (720p I-only) and configs[4] (decode)")
     ap.add_argument("--e2e", type=int, default=1, help="also time the PCIe-inclusive path (pinned host pictures in, host RBSP out)")
+    ap.add_argument("--resolve-wgs", type=int, default=0, help="workgroups of the persistent motion-chain launch (0 = library default)")
+    ap.add_argument("--resolve-group", type=int, default=0, help="streams per ticket group of the motion chain (0 = library default)")
     ap.add_argument("--dist-backend", default=os.environ.get("FER_BENCH_BACKEND", "nccl"),
                     help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal: several ranks may share GPU 0)")
     args = ap.parse_args()
@@ -210,6 +212,11 @@ def main():
                        intra_every=GOP) for i in range(NC)]
     nmb = encs[0].nmb
     fsz = W * H * 3 // 2
+    for e in encs:
+        if args.resolve_wgs:
+            e.tune(1, args.resolve_wgs)
+        if args.resolve_group:
+            e.tune(2, args.resolve_group)
 
     def run_ctx(i, sink=None):
         e, fr = encs[i], parts[i]

@@ -192,6 +192,8 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
 #endif
     d.ysz = (size_t)W * H;
     d.csz = d.ysz / 4;
+    d.resolve_wgs = 3072;
+    d.resolve_group = 4;
     {
         int lo = 0, hi = 0;  // numerically lower = higher priority
         if (hipGetDevice(&c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
@@ -249,10 +251,12 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     rc |= dalloc(c, &d.dec_cac, (size_t)128 * S);
     int n = W * H;
     c->sort.tmp_bytes = fer_sort_tmp_bytes(n, S);
-    rc |= dalloc(c, &c->sort.keys_in, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
-    rc |= dalloc(c, &c->sort.keys_out, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
-    rc |= dalloc(c, &c->sort.vals_in, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
-    rc |= dalloc(c, &c->sort.vals_out, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
+    rc |= dalloc(c, &c->sort.recT, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
+    rc |= dalloc(c, &c->sort.rec1, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
+    rc |= dalloc(c, &c->sort.keyT, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
+    rc |= dalloc(c, &c->sort.dig2, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
+    rc |= dalloc(c, &c->sort.skey, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
+    c->sort.rec_tmp = (uint32_t *)c->sort.recT;  // the arrival-order records are dead once the first pass has read them
     uint8_t *tmp = nullptr;
     rc |= dalloc(c, &tmp, decode_only ? (size_t)1 : (size_t)(c->sort.tmp_bytes));
     c->sort.tmp = tmp;
@@ -895,6 +899,23 @@ extern "C" int ferhip_status(ferhip_ctx *c, int *out)
     CK(ctx_sync(c));
     CK(hipMemcpy(out, c->d.status, sizeof(int) * c->d.S, hipMemcpyDeviceToHost));
     return 0;
+}
+
+// launch-shape knobs (results never depend on them)
+extern "C" int ferhip_tune(ferhip_ctx *c, int key, int value)
+{
+    if (!c) return FERHIP_E_ARG;
+    switch (key) {
+    case FERHIP_TUNE_RESOLVE_WGS:
+        if (value < 1 || value > 65535) return FERHIP_E_ARG;
+        c->d.resolve_wgs = value;
+        return 0;
+    case FERHIP_TUNE_RESOLVE_GROUP:
+        if (value < 1) return FERHIP_E_ARG;
+        c->d.resolve_group = value;
+        return 0;
+    default: return FERHIP_E_ARG;
+    }
 }
 
 extern "C" int ferhip_profile(ferhip_ctx *c, int enable)

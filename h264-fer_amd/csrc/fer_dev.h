@@ -71,6 +71,8 @@ struct FerDev {
     unsigned long long *chain64;  // [S][nmb][4] vector | picture serial << 32 | P_Skip << 63, see k_me_resolve
     long long *timing;   // [64] in-kernel wall-clock sums of one probe wavefront (FER_DBG bit 7)
     int serial;          // serial number of the picture being encoded (never 0)
+    int resolve_wgs;     // workgroups of the persistent k_me_resolve launch (ferhip_tune)
+    int resolve_group;   // streams per ticket group of k_me_resolve (ferhip_tune)
     // entropy coding
     uint32_t *mb_bits;   // [S][nmb+1] bit sizes, then exclusive offsets
     uint32_t *bits;      // [S][bits_cap_words] RBSP, big-endian bit order

@@ -3,9 +3,13 @@
 #include "fer_dev.h"
 
 struct FerSortTmp {
-    uint32_t *keys_in, *keys_out;
-    uint32_t *vals_in, *vals_out;
-    void *tmp;
+    uint4 *recT;        // [S][W][H] plane-0 records + position in arrival order (k_feat0)
+    uint4 *rec1;        // [S][n] the same after the first radix pass
+    uint16_t *keyT;     // [S][W][H] sort keys in arrival order
+    uint8_t *dig2;      // [S][n] high digit of the keys after the first pass
+    uint16_t *skey;     // [S][n] sorted keys
+    uint32_t *rec_tmp;  // [S][n][3] plain sorted records of streams that take the reference's mis-filed layout (aliases recT)
+    void *tmp;          // digit histograms
     size_t tmp_bytes;
 };
 

@@ -60,9 +60,9 @@ __device__ __forceinline__ void wl_insert(WList &L, int K, int lane, bool valid,
 // it is built from few, wide steps:
 //   1. T0 = the need-th smallest per-lane minimum -- an upper bound of the need-th smallest
 //      candidate (one rank computation over 64 LDS words),
-//   2. the candidates <= T0 are compacted in arrival order (typically 1.2-1.5 x need of them),
-//   3. their exact rank by (metric << 6 | compacted position) places the winners.
-// More than 64 survivors of step 2 or metrics >= 2^26 take the binary-search route instead.
+//   2. the candidates <= T0 (typically 1.2-1.5 x need of them) are gathered in LDS, in no particular order,
+//   3. their exact rank by (metric << 11 | arrival index) places the winners.
+// More than 64 survivors of step 2 or a T0 >= 2^21 take the binary-search route instead.
 // v[u] < 0 marks an invalid candidate; raw(u) is a cheap tag of the lane's candidate u that travels with it,
 // fin(tag) turns the tag of a winner into its packed vector (evaluated once per list slot).  sel = 256 ints of 16-byte aligned LDS owned by the wavefront.
 // sel is private to ONE wavefront: its LDS operations execute in program order, so ordering them needs no
@@ -109,6 +109,7 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
         const unsigned mykey = lmin != 0x7fffffff ? ((unsigned)lmin << 6) | (unsigned)lane : 0xffffffffu;
         A[lane] = mykey;
         B[lane] = 0xffffffffu;
+        if (lane == 0) Di[63] = 0;  // slot counter of the compaction below (Di[0 .. need-1] are written much later)
         WAVE_LDS_SYNC();
         const int rk = lds_rank64(A, mykey);
         const unsigned long long hit = __ballot(rk == need - 1);
@@ -117,17 +118,26 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
             unsigned tk = (unsigned)lane_bcast((int)mykey, __ffsll((long long)hit) - 1);
             if (tk != 0xffffffffu) T0 = (int)(tk >> 6);
         }
-        c = 0;
+        // The candidates <= T0 are gathered in NO particular order (an LDS counter hands out the slots, batches
+        // without survivors cost a compare and a branch); what orders them is the key metric << 11 | arrival index,
+        // exact as long as the survivors' metrics stay below 2^21 (they are the smallest ones; larger takes the
+        // general route).
+        if (T0 < (1 << 21) && NB * 64 <= 2048) {
 #pragma unroll
-        for (int u = 0; u < NB; u++) {
-            bool take = v[u] >= 0 && v[u] <= T0;
-            unsigned long long mk = __ballot(take);
-            int pos = c + __popcll(mk & lt);
-            if (take && pos < 64) {
-                B[pos] = ((unsigned)v[u] << 6) | (unsigned)pos;
-                Ci[pos] = raw(u);
+            for (int u = 0; u < NB; u++) {
+                const bool take = v[u] >= 0 && v[u] <= T0;
+                if (__any(take)) {
+                    if (take) {
+                        const int slot = atomicAdd(&Di[63], 1);
+                        if (slot < 64) {
+                            B[slot] = ((unsigned)v[u] << 11) | (unsigned)(u * 64 + lane);
+                            Ci[slot] = raw(u);
+                        }
+                    }
+                }
             }
-            c += __popcll(mk);
+            WAVE_LDS_SYNC();
+            c = Di[63];
         }
     }
     if (c <= 64) {
@@ -137,7 +147,7 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
         const int rk = lds_rank64(B, mine);
         WAVE_LDS_SYNC();
         if (lane < c && rk < need) {
-            A[rk] = mine >> 6;
+            A[rk] = mine >> 11;
             Di[rk] = mypay;
         }
         WAVE_LDS_SYNC();
@@ -345,6 +355,64 @@ __device__ __forceinline__ int sad8_rows(const uint8_t *__restrict__ Ps, size_t 
     return sad_row_reduce(r, s0, s1);
 }
 
+// The same SAD, ONE CANDIDATE PER LANE: the lane walks the eight rows of the block at its own vector; the source
+// block is wave-uniform (scalar registers), so nothing crosses lanes.  Eight lanes per candidate (above) cost a
+// round of address arithmetic, loads and a cross-lane reduction per 8 candidates; a list of 17 or 33 candidates
+// is one pass here.
+struct SrcBlk {
+    uint32_t lo[8], hi[8];
+};
+__device__ __forceinline__ SrcBlk src_block_load(const uint8_t *__restrict__ Y, int W, int sx, int sy)
+{
+    SrcBlk b;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t *q = (const uint32_t *)(Y + (size_t)(sy + r) * W + sx);  // wave-uniform address: scalar loads
+        b.lo[r] = __builtin_amdgcn_readfirstlane((int)q[0]);
+        b.hi[r] = __builtin_amdgcn_readfirstlane((int)q[1]);
+    }
+    return b;
+}
+__device__ __forceinline__ int sad_lane(const uint8_t *__restrict__ Ps, size_t ysz, int W, int H, int sx, int sy, int mvx, int mvy,
+                                        const SrcBlk &S)
+{
+    const int xPi = iclamp(sx + (mvx >> 2), 0, W - 1), yPi = iclamp(sy + (mvy >> 2), 0, H - 1);
+    const uint32_t sh = (uint32_t)(xPi & 3);  // planes and rows start on 16-byte boundaries
+    const uint8_t *p0 = Ps + (size_t)((mvx & 3) + (mvy & 3) * 4) * ysz + (xPi & ~3);
+    const int nv = W - xPi;
+    uint32_t w[8][3];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t *a = (const uint32_t *)(p0 + (size_t)min(yPi + r, H - 1) * W);
+        w[r][0] = a[0];
+        w[r][1] = a[1];
+        w[r][2] = a[2];
+    }
+    uint32_t sad = 0;
+    if (__any(nv < 8)) {  // right edge: the reference clamps each column (F/moestimation.cpp:189)
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint32_t r0 = __builtin_amdgcn_alignbyte(w[r][1], w[r][0], sh), r1 = __builtin_amdgcn_alignbyte(w[r][2], w[r][1], sh);
+            if (nv < 8) {
+                unsigned long long v = ((unsigned long long)r1 << 32) | r0;
+                unsigned long long last = (v >> (8 * (nv - 1))) & 0xffull;
+                unsigned long long keep = (1ull << (8 * nv)) - 1ull;
+                v = (v & keep) | ((last * 0x0101010101010101ull) & ~keep);
+                r0 = (uint32_t)v;
+                r1 = (uint32_t)(v >> 32);
+            }
+            sad = __builtin_amdgcn_sad_u8(r1, S.hi[r], __builtin_amdgcn_sad_u8(r0, S.lo[r], sad));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t r0 = __builtin_amdgcn_alignbyte(w[r][1], w[r][0], sh), r1 = __builtin_amdgcn_alignbyte(w[r][2], w[r][1], sh);
+            sad = __builtin_amdgcn_sad_u8(r1, S.hi[r], __builtin_amdgcn_sad_u8(r0, S.lo[r], sad));
+        }
+    }
+    return (int)sad;
+}
+
 // ------------------------------------------------------------------ k_me_pre
 #define ME_WIDE_LDS 1156  // (2*16+2)^2: WindowSize <= 32 takes the LDS route (4.6 KB per wave)
 #define ME_SEL_NB 25      // 64-candidate batches of stage 3 at WindowSize 32: 18 wide + 7 local
@@ -357,7 +425,10 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     const int lane = threadIdx.x;
     const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;
-    const int mb = blockIdx.x >> 2, part = blockIdx.x & 3;
+    // workgroups are dealt round-robin over the 8 XCDs: give each XCD a contiguous eighth of the picture, so that the
+    // search windows of the partitions it works on overlap in ITS L2
+    const unsigned bx = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int mb = (int)(bx >> 2), part = (int)(bx & 3);
     const int W = d.W, H = d.H;
     const size_t ysz = d.ysz;
     const uint8_t *Y = d.curY + (size_t)s * ysz;
@@ -367,7 +438,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
 
 #ifdef FER_PROBE
-    const bool probe = FER_DBGF(d, 128) && s == 0 && (blockIdx.x % 997) == 5;  // a sample of partitions reports its time split
+    const bool probe = FER_DBGF(d, 128) && s == 0 && (bx % 997) == 5;  // a sample of partitions reports its time split
     long long tmark = probe ? wall_clock64() : 0;
 #define PP_MARK(k)                                                          \
     if (probe) {                                                            \
@@ -394,11 +465,6 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     }
     const SuPk sp = su_pack(su);
     PP_MARK(0)
-
-    // source rows for the SAD groups (sx is a multiple of 8: aligned dwords)
-    const int row = lane & 7;
-    const uint32_t src0 = *(const uint32_t *)(Y + (size_t)(sy + row) * W + sx);
-    const uint32_t src1 = *(const uint32_t *)(Y + (size_t)(sy + row) * W + sx + 4);
 
     // ---- stage 3: MEstimation(+-W/2, frac 0, centre 0) then MEstimation(+-W/16, 16 fracs, centre 0)
     WList L;
@@ -528,25 +594,15 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
         }
     }
     const int n3 = __popcll(__ballot(lane < 33 && L.m < 100000000));
-    if (!FER_DBGF(d, 4)) {  // SADs of the survivors: all five rounds' rows requested before the first reduction
-        SadRow rr[5];
-        int xyr[5];
-#pragma unroll
-        for (int r = 0; r < 5; r++) {
-            int j = r * 8 + (lane >> 3);
-            xyr[r] = __shfl(L.xy, j < 33 ? j : 0);
-            rr[r] = sad_row_load(Ps, ysz, W, H, sx, sy, unp_x(xyr[r]), unp_y(xyr[r]), row);
-        }
-#pragma unroll
-        for (int r = 0; r < 5; r++) {
-            int j = r * 8 + (lane >> 3);
-            int sad = sad_row_reduce(rr[r], src0, src1);
-            if (j < n3 && row == 0) {
-                int *o = d.st3 + (pidx * 33 + j) * 3;
-                o[0] = unp_x(xyr[r]);
-                o[1] = unp_y(xyr[r]);
-                o[2] = sad;
-            }
+    if (!FER_DBGF(d, 4)) {  // SADs of the survivors: list slot j lives in lane j
+        const SrcBlk SB = src_block_load(Y, W, sx, sy);
+        const int cx = unp_x(L.xy), cy = unp_y(L.xy);
+        const int sad = sad_lane(Ps, ysz, W, H, sx, sy, lane < n3 ? cx : 0, lane < n3 ? cy : 0, SB);
+        if (lane < n3) {
+            int *o = d.st3 + (pidx * 33 + lane) * 3;
+            o[0] = cx;
+            o[1] = cy;
+            o[2] = sad;
         }
     }
     if (lane == 0) d.st3n[pidx] = n3;
@@ -591,7 +647,7 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
     int jn = 0, side = 0;             // next slice to open
     unsigned cur = 0, end = 0;        // rest of the open slice
     int cur_a = 0, cur_last = 0;      // its bucket; 1 = second side of its j (the stop test follows it)
-    unsigned kl0 = 0, kl1 = 0, kh0 = 0, kh1 = 0;
+    unsigned kb = 0;                  // bucket bounds of 16 steps, see gen
     bool open = false, done = false;
     // next batch: start index, entry count (0 = nothing to read), bucket, flags (1 = stop test after it, 2 = end of walk)
     auto gen = [&](unsigned &b_start, int &b_cnt, int &b_a, int &b_flags) {
@@ -609,23 +665,22 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
                 b_flags = 2;
                 return;
             }
-            if (side == 0 && (jn & 63) == 0) {  // bucket bounds of the next 64 steps, one step per lane
-                int al = su[0] - (jn + lane), ah = su[0] + (jn + lane);
-                bool vl = al >= 0 && al < 16384, vh = ah >= 0 && ah < 16384;
+            if (side == 0 && (jn & 15) == 0) {
+                // bucket bounds of the next 16 steps in ONE gather: lane = which * 16 + step, which = 0 / 1 first and
+                // end of the low side's slice, 2 / 3 of the high side's (most walks end within a few steps)
+                const int which = lane >> 4, jj = jn + (lane & 15);
+                const int a = (which & 2) ? su[0] + jj : su[0] - jj;
+                const bool va = a >= 0 && a < 16384;
+                unsigned v = 0u;
                 if (!quirk) {
-                    kl0 = vl ? kol2[(size_t)al * kt + t_lo] : 0u;
-                    kl1 = vl ? kol2[(size_t)al * kt + t_hi + 1] : 0u;
-                    kh0 = vh ? kol2[(size_t)ah * kt + t_lo] : 0u;
-                    kh1 = vh ? kol2[(size_t)ah * kt + t_hi + 1] : 0u;
+                    if (va) v = kol2[(size_t)a * kt + ((which & 1) ? t_hi + 1 : t_lo)];
                 } else {
-                    kl0 = vl ? qstart(al) : 0u;
-                    kl1 = vl ? qstart(al + 1) : 0u;
-                    kh0 = vh ? qstart(ah) : 0u;
-                    kh1 = vh ? qstart(ah + 1) : 0u;
+                    if (va) v = qstart(a + (which & 1));
                 }
+                kb = v;
             }
-            cur = (unsigned)lane_bcast((int)(side ? kh0 : kl0), jn & 63);
-            end = (unsigned)lane_bcast((int)(side ? kh1 : kl1), jn & 63);
+            cur = (unsigned)lane_bcast((int)kb, (jn & 15) + (side ? 32 : 0));
+            end = (unsigned)lane_bcast((int)kb, (jn & 15) + (side ? 48 : 16));
             cur_a = side ? su[0] + jn : su[0] - jn;
             cur_last = side;
             open = true;
@@ -703,6 +758,8 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
     const int lane = threadIdx.x;
     const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;
+    // plain picture order: neighbouring partitions enter the bucket index at the same column tiles and at nearby sums,
+    // so its lines are shared (ordering the partitions by sum, or giving each XCD a band of the picture, lost 20 %)
     const int mb = blockIdx.x >> 2, part = blockIdx.x & 3;
     const int W = d.W;
     const uint8_t *Y = d.curY + (size_t)s * d.ysz;
@@ -725,37 +782,18 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
     if (lane == 0) d.st2n[pidx] = tren;
 }
 
-// SAD of up to K list entries, 8 per round (lane = candidate*8 + row), and the lane's best
-// (cost << 6 | list index) over its rounds: cost = SAD + |mv - mvp| (F/moestimation.cpp:460-468).
-// No wave-level reduction in here, so that the loads of several lists can be in flight together.
+// SAD of the K list entries (slot j in lane j) and the lane's key (cost << 6 | list index):
+// cost = SAD + |mv - mvp| (F/moestimation.cpp:460-468).  No wave-level reduction in here.
 template <int K>
 __device__ __forceinline__ void sad_keys(const WList &L, int cnt, int lane, const uint8_t *__restrict__ Ps, size_t ysz,
-                                         int W, int H, int sx, int sy, uint32_t src0, uint32_t src1, int mvpx, int mvpy,
+                                         int W, int H, int sx, int sy, const SrcBlk &SB, int mvpx, int mvpy,
                                          int &best, int &bestxy)
 {
-    constexpr int ROUNDS = (K + 7) / 8;
-    const int row = lane & 7;
-    SadRow rr[ROUNDS];
-    int xyr[ROUNDS];
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        int j = r * 8 + (lane >> 3);
-        xyr[r] = __shfl(L.xy, j < K ? j : 0);
-        rr[r] = sad_row_load(Ps, ysz, W, H, sx, sy, unp_x(xyr[r]), unp_y(xyr[r]), row);
-    }
-    best = 0x7fffffff;
-    bestxy = 0;
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        int j = r * 8 + (lane >> 3);
-        int cxv = unp_x(xyr[r]), cyv = unp_y(xyr[r]);
-        int sad = sad_row_reduce(rr[r], src0, src1);
-        int key = j < cnt ? ((sad + iabs(cxv - mvpx) + iabs(cyv - mvpy)) << 6) | j : 0x7fffffff;
-        if (key < best) {
-            best = key;
-            bestxy = xyr[r];
-        }
-    }
+    const bool on = lane < cnt && lane < K;
+    const int cxv = on ? unp_x(L.xy) : 0, cyv = on ? unp_y(L.xy) : 0;
+    const int sad = sad_lane(Ps, ysz, W, H, sx, sy, cxv, cyv, SB);
+    best = on ? ((sad + iabs(cxv - mvpx) + iabs(cyv - mvpy)) << 6) | lane : 0x7fffffff;
+    bestxy = L.xy;
 }
 // the strict-< first-minimum update of the reference, in list order, from per-lane bests
 __device__ __forceinline__ void take_best(int best, int bestxy, int &bmin, int &bx, int &by)
@@ -798,7 +836,7 @@ struct ResPre {  // predictor-independent operands of one partition (role 1 need
     int2 e2[FER_ST2_CAP / 64];
     int c3x, c3y, c3s;
     int su[5];
-    uint32_t src0, src1;
+    SrcBlk sb;  // source block (wave-uniform)
 };
 
 __device__ __forceinline__ void res_prefetch(const FerDev &d, int s, int gx, int gy, int lane, int role, ResPre &p)
@@ -824,10 +862,7 @@ __device__ __forceinline__ void res_prefetch(const FerDev &d, int s, int gx, int
     }
 #pragma unroll
     for (int k = 0; k < 5; k++) p.su[k] = d.suma[pidx * 5 + k];
-    const uint8_t *Y = d.curY + (size_t)s * d.ysz;
-    const int row = lane & 7;
-    p.src0 = *(const uint32_t *)(Y + (size_t)(gy * 8 + row) * d.W + gx * 8);
-    p.src1 = *(const uint32_t *)(Y + (size_t)(gy * 8 + row) * d.W + gx * 8 + 4);
+    p.sb = src_block_load(d.curY + (size_t)s * d.ysz, d.W, gx * 8, gy * 8);
 }
 
 // Vectors travel between rows as self-validating 64-bit words in d.chain64 [S][nmb][4]:
@@ -974,7 +1009,7 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
     }
     const int cnt1 = __popcll(__ballot(lane < 17 && L1.m < 100000000));
     int b1, b1xy;
-    sad_keys<17>(L1, cnt1, lane, Ps, ysz, W, H, sx, sy, P.src0, P.src1, mvpx, mvpy, b1, b1xy);
+    sad_keys<17>(L1, cnt1, lane, Ps, ysz, W, H, sx, sy, P.sb, mvpx, mvpy, b1, b1xy);
     wave_best(b1, b1xy, wkey, wxy);
     return false;
 }
@@ -1021,7 +1056,7 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
     }
     const int cnt2 = __popcll(__ballot(lane < 33 && L2.m < 100000000));
     int b2, b2xy;
-    sad_keys<33>(L2, cnt2, lane, Ps, ysz, W, H, sx, sy, P.src0, P.src1, mvpx, mvpy, b2, b2xy);
+    sad_keys<33>(L2, cnt2, lane, Ps, ysz, W, H, sx, sy, P.sb, mvpx, mvpy, b2, b2xy);
     wave_best(b2, b2xy, k2, xy2);
     int key = 0x7fffffff;
     if (lane < P.n3) key = ((P.c3s + iabs(P.c3x - mvpx) + iabs(P.c3y - mvpy)) << 6) | lane;
@@ -1075,14 +1110,28 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
     // Row tickets: rows of all streams in row-major order.  The launch is capped at a share of the GPU's
     // workgroup slots (other contexts' kernels keep finding free slots); a workgroup that finishes a row takes
     // the next ticket.
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int nq = d.S >= 16 ? 8 : 1;                 // queues
+    const int q = nq == 8 ? (xcc & 7) : 0;            // this workgroup's queue
+    const int nsq = (d.S - q + nq - 1) / nq;          // streams q, q + nq, ... of the queue
     for (;;) {
     __syncthreads();
-    if (threadIdx.x == 0) xch[0] = atomicAdd(d.chain, 1);
+    // One ticket queue per XCD (when there are enough streams): stream s belongs to XCD s % 8, and an XCD takes its
+    // streams `resolve_group` at a time, row-major inside the group.  All rows of a stream then run on ONE XCD: the
+    // window a partition reads was fetched into that XCD's L2 by the row above a few steps earlier, and the rows in
+    // flight belong to few streams, so the working set fits.  Which XCD a workgroup runs on is read from the hardware
+    // (HW_REG_XCC_ID); nothing depends on how workgroups are placed.
+    if (threadIdx.x == 0) xch[0] = atomicAdd(d.chain + q, 1);
     __syncthreads();
     const int t = xch[0];
     __syncthreads();
-    const int gy = t / d.S, s = t - gy * d.S;
-    if (gy >= gh) return;
+    const int G = d.resolve_group;
+    const int grp = t / (gh * G), rr = t - grp * (gh * G);
+    const int k0 = grp * G, kn = min(G, nsq - k0);  // streams of this group, as indices into the queue's stream list
+    if (k0 >= nsq) return;
+    const int gy = rr / kn, s = q + nq * (k0 + (rr - gy * kn));
+    if (gy >= gh) continue;  // short last group: its tickets beyond gh * kn name no row
     if (d.hdr[s * 4 + 3] != 0) continue;  // not a P picture: nobody waits on these rows
     unsigned long long *chw = d.chain64 + (size_t)s * d.nmb * 4;
     int *mbt = d.mb_type + (size_t)s * d.nmb;
@@ -1300,12 +1349,8 @@ void fer_launch_me_walk(const FerDev &d, hipStream_t st)
 void fer_launch_me_resolve(const FerDev &d, hipStream_t st)
 {
     const int gh = 2 * d.mbh;
-    hipMemsetAsync(d.chain, 0, sizeof(int), st);
-#ifdef FER_PROBE
-    static const int cap = getenv("FER_RESOLVE_WGS") ? atoi(getenv("FER_RESOLVE_WGS")) : 1536;
-#else
-    const int cap = 1536;
-#endif
+    hipMemsetAsync(d.chain, 0, sizeof(int) * 8, st);
+    const int cap = d.resolve_wgs;
     dim3 g(min(gh * d.S, max(cap, 1)));
     if (d.window == 32)
         hipLaunchKernelGGL(k_me_resolve<32>, g, dim3(128), 0, st, d);

@@ -124,7 +124,6 @@ __global__ __launch_bounds__(256) void k_features(FerDev d)
     const uint8_t *P = d.interp + ((size_t)s * 16 + f) * d.ysz;
     const int y0 = strip * FS_ROWS, y1 = min(y0 + FS_ROWS, H);  // output rows [y0, y1)
     uint32_t *out = (uint32_t *)(d.feat + (size_t)s * 96 * d.ysz);
-    uint32_t *out0 = (uint32_t *)(d.feat0 + (size_t)s * 6 * d.ysz);
     const int sh = (int)((uintptr_t)(P + x) & 3);  // W is a multiple of 16: the same byte offset in every row
     const int nv = W - x;
     int h8[8], h4[8], hc[8];
@@ -158,91 +157,294 @@ __global__ __launch_bounds__(256) void k_features(FerDev d)
                 __builtin_nontemporal_store(a, o);
                 __builtin_nontemporal_store(b, o + 1);
                 __builtin_nontemporal_store(c, o + 2);
-                if (f == 0) {
-                    uint32_t *o0 = out0 + pos * 3;
-                    o0[0] = a;
-                    o0[1] = b;
-                    o0[2] = c;
-                }
             }
         }
     }
 }
 
-// ------------------------------------------------------------------ sort by 8x8 sum
-// keys in arrival order b = tx*H + ty (the reference scans columns, F/moestimation.cpp:142-151)
-__global__ void k_sort_keys(FerDev d, uint32_t *keys, uint32_t *vals)
+// ------------------------------------------------------------------ k_feat0
+// Plane 0 of the feature table straight from the reference luma (interpolated plane 0 IS the reference picture):
+//   feat0 [H][W]   12-byte records (k0|k1, k2|k3, k4) row-major, what the wide integer search streams;
+//   recT  [W][H]   16-byte records (k0|k1, k2|k3, k4, tx<<16|ty) in ARRIVAL order b = tx*H + ty of the reference's
+//                  counting sort (F/moestimation.cpp:142-151 scans columns) -- the input of the radix passes;
+//   keyT  [W][H]   the sort key k0 alone (uint16), so that the histogram passes read 2 bytes per position.
+// One workgroup per 64x64 tile of positions: the (64+7)^2 samples (replicated beyond the picture, like the
+// reference's 8-pixel padding :107-115) go to LDS once; a thread owns a column of 16 positions, takes the horizontal
+// partial sums of each input row with v_sad_u8 and keeps the last 8 rows in registers (the scheme of k_features);
+// finished records are transposed through LDS so that both outputs are written in long contiguous runs.
+#define F0_T 64
+__global__ __launch_bounds__(256) void k_feat0(FerDev d, uint4 *recT, uint16_t *keyT)
 {
-    const int s = blockIdx.y;
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    int n = d.W * d.H;
-    if (b >= n) return;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[F0_T + 7][F0_T + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[F0_T][F0_T + 1][3];  // [x][y]: + 1 breaks the bank stride
+    const int s = blockIdx.z;
     if (d.hdr[s * 4 + 3] != 0) return;
-    int tx = b / d.H, ty = b % d.H;
-    uint16_t k = d.feat0[((size_t)s * d.ysz + (size_t)ty * d.W + tx) * 6];
-    keys[(size_t)s * n + b] = k;
-    vals[(size_t)s * n + b] = ((uint32_t)tx << 16) | (uint32_t)ty;
-    if (k == 0) atomicAdd(&d.zero_cnt[s], 1);  // the reference mis-files sum 0: see k_sort_finish
+    const int W = d.W, H = d.H;
+    const uint8_t *R = d.refY + (size_t)s * d.ysz;
+    const int x0 = blockIdx.x * F0_T, y0 = blockIdx.y * F0_T;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (F0_T + 7) * ((F0_T + 8) / 4); i += 256) {
+        const int r = i / ((F0_T + 8) / 4), c4 = (i % ((F0_T + 8) / 4)) * 4;
+        const int y = min(y0 + r, H - 1);
+        uint32_t v;
+        if (x0 + c4 + 3 < W) {
+            v = *(const uint32_t *)(R + (size_t)y * W + x0 + c4);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= (uint32_t)R[(size_t)y * W + min(x0 + c4 + k, W - 1)] << (8 * k);
+        }
+        *(uint32_t *)&tile[r][c4] = v;
+    }
+    __syncthreads();
+    const int x = tid & 63, g = tid >> 6;  // column of the tile, group of 16 rows
+    const int sh = x & 3;
+    int h8[8], h4[8], hc[8];
+    int nzero = 0;
+#pragma unroll
+    for (int j = 0; j < 16 + 7; j++) {
+        const int r = g * 16 + j;  // input row of the tile; completes the window of output row r - 7
+        const uint32_t *w = (const uint32_t *)&tile[r][x & ~3];
+        const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)sh);
+        const uint32_t hi = __builtin_amdgcn_alignbyte(w[2], w[1], (uint32_t)sh);
+        const int a4 = (int)__builtin_amdgcn_sad_u8(lo, 0u, 0u);
+        h4[j & 7] = a4;
+        h8[j & 7] = (int)__builtin_amdgcn_sad_u8(hi, 0u, (uint32_t)a4);
+        hc[j & 7] = (int)__builtin_amdgcn_sad_u8(hi & 0xffffu, 0u, __builtin_amdgcn_sad_u8(lo & 0xffffu, 0u, 0u));
+        if (j >= 7) {
+            const int yo = r - 7;  // window rows yo .. yo+7 sit in slots (j + 1 + k) & 7
+            int k0 = 0, k2 = 0, k4 = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                k0 += h8[k];
+                k2 += h4[k];
+                k4 += hc[k];
+            }
+            const int k1 = h8[(j + 1) & 7] + h8[(j + 2) & 7] + h8[(j + 3) & 7] + h8[(j + 4) & 7];
+            const int k3 = h8[(j + 1) & 7] + h8[(j + 2) & 7] + h8[(j + 5) & 7] + h8[(j + 6) & 7];
+            const uint32_t a = (uint32_t)k0 | ((uint32_t)k1 << 16), b = (uint32_t)k2 | ((uint32_t)k3 << 16), c = (uint32_t)k4;
+            stage[x][yo][0] = a;
+            stage[x][yo][1] = b;
+            stage[x][yo][2] = c;
+            const int gx = x0 + x, gy = y0 + yo;
+            if (gx < W && gy < H) {
+                uint32_t *o = (uint32_t *)(d.feat0 + ((size_t)s * d.ysz + (size_t)gy * W + gx) * 6);
+                o[0] = a;
+                o[1] = b;
+                o[2] = c;
+                nzero += k0 == 0;
+            }
+        }
+    }
+    if (__any(nzero)) {  // the reference mis-files sum 0: see k_sort_quirk
+        const int tot = wave_sum(nzero);
+        if ((tid & 63) == 0 && tot) atomicAdd(&d.zero_cnt[s], tot);
+    }
+    __syncthreads();
+    // column-major outputs: thread = (column, 16 consecutive rows of it)
+    for (int i = tid; i < F0_T * F0_T; i += 256) {
+        const int cx = i >> 6, cy = i & 63;
+        const int gx = x0 + cx, gy = y0 + cy;
+        if (gx < W && gy < H) {
+            const size_t bidx = (size_t)s * d.ysz + (size_t)gx * H + gy;
+            const uint32_t a = stage[cx][cy][0];
+            recT[bidx] = make_uint4(a, stage[cx][cy][1], stage[cx][cy][2], ((uint32_t)gx << 16) | (uint32_t)gy);
+            keyT[bidx] = (uint16_t)(a & 0xffffu);
+        }
+    }
 }
 
-// Payload of the sorted order + the two-level bucket index.  Record i opens every (sum, column tile) bin
-// after its predecessor's up to its own: kol2[bin] = i for those bins (lower bound of the bin in the sorted
-// order).  Gaps are short except at the ends of the sum range; long ones are filled by the whole wavefront.
-//
-// Bucket 0.  The reference's counting sort (F/moestimation.cpp:153-172) leaves bucket 0 out of its prefix sum:
-// with n0 positions of sum 0, every other bucket starts n0 places early (the sorted array is the other
-// positions from 0, its last n0 places keep what the previous picture left there), the k-th sum-0 position
-// is written to place n0 + k, where it replaces, or is replaced by, the regular occupant -- whichever the
-// scatter loop reaches later in arrival order --, bucket 0 reads as [0, 2 n0) and bucket 1 starts at 2 n0.
-// That layout is reproduced here for a stream with n0 > 0 (black areas in full-range content); the walk then
-// scans whole buckets by these rules (walk_buckets).  The index kol2 keeps describing the plain sorted order.
-__device__ __forceinline__ void sort_record(const FerDev &d, int s, uint32_t v, uint32_t *o)
+// ------------------------------------------------------------------ sort by 8x8 sum
+// The order the reference's counting sort produces (F/moestimation.cpp:140-172) is "by sum, ties in arrival order",
+// i.e. a stable sort of the arrival sequence by a 14-bit key (sums <= 64 * 255).  Two stable LSD radix passes of
+// 7 bits; each pass is three launches -- per-tile digit histograms, one exclusive scan per stream over (digit, tile),
+// stable scatter -- and no block ever waits on another one, so the sort keeps its speed when another context's
+// kernels share the GPU.  The 16-byte records travel with their keys (no gather at the end): pass 1 reads them in
+// arrival order, pass 2 writes the 12-byte records the bucket walk streams, the sorted positions and the sorted keys.
+// Streams are independent segments (blockIdx.y).
+#define RS_THREADS 256
+#define RS_ITEMS 16
+#define RS_TILE (RS_THREADS * RS_ITEMS)
+#define RS_BITS 7
+#define RS_ND (1 << RS_BITS)
+
+// digit of element idx for this pass: pass 0 = low 7 bits of the key, pass 1 = the high 7 bits kept by pass 0
+__device__ __forceinline__ unsigned rs_digit(const uint16_t *keyT, const uint8_t *dig2, int pass, size_t idx)
 {
-    int tx = v >> 16, ty = v & 0xffff;
-    const uint32_t *r = (const uint32_t *)(d.feat0 + ((size_t)s * d.ysz + (size_t)ty * d.W + tx) * 6);
-    uint32_t a = r[0], b = r[1], c = r[2];  // k0|k1<<16, k2|k3<<16, k4
-    o[0] = v;
-    o[1] = (a >> 16) | (b << 16);
-    o[2] = (b >> 16) | (c << 16);
+    return pass == 0 ? (unsigned)(keyT[idx] & (RS_ND - 1)) : (unsigned)dig2[idx];
 }
 
-__global__ __launch_bounds__(256) void k_sort_finish(FerDev d, const uint32_t *skeys, const uint32_t *svals)
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(FerDev d, const uint16_t *keyT, const uint8_t *dig2, uint32_t *hist, int ntiles,
+                                                       int pass)
+{
+    __shared__ unsigned h[RS_ND];
+    const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    if (d.hdr[s * 4 + 3] != 0) return;
+    const int n = d.W * d.H;
+    const size_t g0 = (size_t)s * n;
+    if (tid < RS_ND) h[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        int idx = tile * RS_TILE + i * RS_THREADS + tid;
+        if (idx < n) atomicAdd(&h[rs_digit(keyT, dig2, pass, g0 + idx)], 1u);
+    }
+    __syncthreads();
+    if (tid < RS_ND) hist[((size_t)s * RS_ND + tid) * ntiles + tile] = h[tid];  // digit-major: the scan order is the output order
+}
+
+__global__ __launch_bounds__(256) void k_rs_scan(FerDev d, uint32_t *hist, int ntiles)
+{
+    __shared__ unsigned part[256];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (d.hdr[s * 4 + 3] != 0) return;
+    uint32_t *h = hist + (size_t)s * RS_ND * ntiles;
+    const int n = RS_ND * ntiles;
+    const int per = (n + 255) / 256;
+    const int b0 = min(tid * per, n), b1 = min(b0 + per, n);
+    unsigned sum = 0;
+    for (int i = b0; i < b1; i++) sum += h[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        unsigned v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = tid ? part[tid - 1] : 0;
+    for (int i = b0; i < b1; i++) {
+        unsigned v = h[i];
+        h[i] = run;
+        run += v;
+    }
+}
+
+// Stable scatter of one tile.  A wavefront owns a contiguous quarter of the tile and walks it in arrival order,
+// 64 items per round: the rank of an item among the earlier items of its digit comes from ballot matching plus a
+// per-wavefront running count per digit.  The tile is then put in output order inside LDS (digit runs one after the
+// other) and written out, so that neighbouring threads write neighbouring addresses of the same digit run.
+// pass 0: in = recT (arrival order), out = rec1 (16 B) + dig2 (high digit);  pass 1: in = rec1, out = final arrays.
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint16_t *keyT, const uint8_t *dig2_in, const uint4 *rec_in,
+                                                          uint4 *rec1_out, uint8_t *dig2_out, uint32_t *rec_tmp, uint16_t *skey,
+                                                          const uint32_t *hist, int ntiles, int pass)
+{
+    __shared__ unsigned run[RS_THREADS / 64][RS_ND];  // per wavefront: items of each digit seen so far
+    __shared__ unsigned base[RS_ND], dstart[RS_ND];
+    __shared__ unsigned wsum[RS_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) uint4 srec[RS_TILE];
+    const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    if (d.hdr[s * 4 + 3] != 0) return;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int n = d.W * d.H;
+    const size_t g0 = (size_t)s * n;
+    if (tid < RS_ND) {
+#pragma unroll
+        for (int w = 0; w < RS_THREADS / 64; w++) run[w][tid] = 0;
+        base[tid] = hist[((size_t)s * RS_ND + tid) * ntiles + tile];
+    }
+    __syncthreads();
+    const int w0 = tile * RS_TILE + wv * (RS_TILE / (RS_THREADS / 64));
+    unsigned dg[RS_ITEMS], rk[RS_ITEMS];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const int idx = w0 + r * 64 + lane;
+        dg[r] = idx < n ? rs_digit(keyT, dig2_in, pass, g0 + idx) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const bool ok = w0 + r * 64 + lane < n;
+        unsigned long long peers = __ballot(ok);  // lanes with the same digit
+#pragma unroll
+        for (int b = 0; b < RS_BITS; b++) {
+            unsigned long long bal = __ballot((dg[r] >> b) & 1);
+            peers &= ((dg[r] >> b) & 1) ? bal : ~bal;
+        }
+        const unsigned before = run[wv][dg[r]];
+        rk[r] = before + (unsigned)__popcll(peers & lt);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (ok && (peers & lt) == 0) run[wv][dg[r]] = before + (unsigned)__popcll(peers);  // first lane of the group
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    unsigned tot = 0;
+    if (tid < RS_ND) {  // digit tid: wavefront totals -> offsets inside the digit's run of this tile
+#pragma unroll
+        for (int w = 0; w < RS_THREADS / 64; w++) {
+            unsigned c = run[w][tid];
+            run[w][tid] = tot;
+            tot += c;
+        }
+    }
+    {  // exclusive prefix of the tile's digit totals (RS_ND values, threads 0 .. RS_ND-1 = wavefronts 0 and 1)
+        unsigned inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        unsigned before = 0;
+        for (int w = 0; w < wv; w++) before += wsum[w];
+        if (tid < RS_ND) dstart[tid] = before + inc - tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const int idx = w0 + r * 64 + lane;
+        if (idx < n) srec[dstart[dg[r]] + run[wv][dg[r]] + rk[r]] = rec_in[g0 + idx];
+    }
+    __syncthreads();
+    const int cnt = min(RS_TILE, n - tile * RS_TILE);
+    if (pass == 0) {
+        for (int i = tid; i < cnt; i += RS_THREADS) {
+            const uint4 v = srec[i];
+            const unsigned key = v.x & 0xffffu;
+            const unsigned dgi = key & (RS_ND - 1);
+            const size_t pos = g0 + base[dgi] + ((unsigned)i - dstart[dgi]);
+            rec1_out[pos] = v;
+            dig2_out[pos] = (uint8_t)(key >> RS_BITS);
+        }
+    } else {
+        // a stream with positions of sum 0 gets its final layout from k_sort_quirk: leave the persistent array alone
+        uint32_t *recs = d.zero_cnt[s] > 0 ? rec_tmp : d.sort_rec;
+        for (int i = tid; i < cnt; i += RS_THREADS) {
+            const uint4 v = srec[i];
+            const unsigned key = v.x & 0xffffu;
+            const unsigned dgi = key >> RS_BITS;
+            const size_t pos = g0 + base[dgi] + ((unsigned)i - dstart[dgi]);
+            uint32_t *o = recs + pos * 3;  // {(tx << 16) | ty, k1 | k2 << 16, k3 | k4 << 16}: what the bucket walk reads
+            o[0] = v.w;
+            o[1] = (v.x >> 16) | (v.y << 16);
+            o[2] = (v.y >> 16) | (v.z << 16);
+            d.sort_pos[pos] = v.w;
+            skey[pos] = (uint16_t)key;
+        }
+    }
+}
+
+// Two-level bucket index over the plain sorted order.  Record i opens every (sum, column tile) bin after its
+// predecessor's up to its own: kol2[bin] = i for those bins (lower bound of the bin in the sorted order).  Gaps are
+// short except at the ends of the sum range; long ones are filled by the whole wavefront.
+__global__ __launch_bounds__(256) void k_sort_index(FerDev d, const uint16_t *skey)
 {
     const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = d.W * d.H;
     const int nb = 16384 * d.kt;
-    const int n0 = d.zero_cnt[s];
     uint32_t *kol2 = d.kol2 + (size_t)s * nb;
     const size_t g0 = (size_t)s * n;
     int gap_lo = 0, gap_hi = 0;  // bins [gap_lo, gap_hi) get value gval
     uint32_t gval = 0;
     if (i < n) {
-        const uint32_t v = svals[g0 + i];
-        const int tx = v >> 16;
-        d.sort_pos[g0 + i] = v;
-        if (n0 == 0) {
-            sort_record(d, s, v, d.sort_rec + (g0 + i) * 3);
-        } else if (i >= n0) {  // a regular position: n0 places early, unless the sum-0 position aimed there comes later
-            const int p = i - n0;
-            uint32_t w = v;
-            if (p >= n0 && p < 2 * n0) {
-                const uint32_t z = svals[g0 + p - n0];
-                const int bz = (int)(z >> 16) * d.H + (int)(z & 0xffff), bn = tx * d.H + (int)(v & 0xffff);
-                if (bz > bn) w = z;
-            }
-            sort_record(d, s, w, d.sort_rec + (g0 + p) * 3);
-        } else {  // a sum-0 position: place n0 + i, written here only where no regular position lands
-            const int p = n0 + i;
-            if (p >= n - n0 && p < n) sort_record(d, s, v, d.sort_rec + (g0 + p) * 3);
-        }
-        int bin = (int)(skeys[g0 + i] & 0x7fff) * d.kt + (tx >> d.ktw_shift);
+        const int bin = (int)skey[g0 + i] * d.kt + (int)((d.sort_pos[g0 + i] >> 16) >> d.ktw_shift);
         int prev = -1;
-        if (i > 0) {
-            uint32_t pv = svals[g0 + i - 1];
-            prev = (int)(skeys[g0 + i - 1] & 0x7fff) * d.kt + (int)((pv >> 16) >> d.ktw_shift);
-        }
+        if (i > 0) prev = (int)skey[g0 + i - 1] * d.kt + (int)((d.sort_pos[g0 + i - 1] >> 16) >> d.ktw_shift);
         gap_lo = prev + 1;
         gap_hi = bin + 1;
         gval = (uint32_t)(g0 + i);
@@ -269,165 +471,52 @@ __global__ __launch_bounds__(256) void k_sort_finish(FerDev d, const uint32_t *s
     }
 }
 
-// ---- stable LSD radix sort of one stream's (sum, position) pairs: two passes of 8 + 7 bits ----
-// The order the reference's counting sort produces (F/moestimation.cpp:140-172) is "by sum, ties in arrival
-// order", i.e. a stable sort of the arrival sequence.  Each pass is three launches -- per-tile digit
-// histograms, one exclusive scan per stream over (digit, tile), stable scatter -- and no block ever waits on
-// another one, so the sort keeps its speed when another context's kernels share the GPU (a single-pass
-// look-back sort stalls there).  Streams are independent segments (blockIdx.y).
-#define RS_THREADS 256
-#define RS_ITEMS 16
-#define RS_TILE (RS_THREADS * RS_ITEMS)
-
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(FerDev d, const uint32_t *keys, uint32_t *hist, int ntiles, int shift)
+// Bucket 0.  The reference's counting sort (F/moestimation.cpp:153-172) leaves bucket 0 out of its prefix sum: with
+// n0 positions of sum 0, every other bucket starts n0 places early (the sorted array is the other positions from 0,
+// its last n0 places keep what the previous picture left there), the k-th sum-0 position is written to place n0 + k,
+// where it replaces, or is replaced by, the regular occupant -- whichever the scatter loop reaches later in arrival
+// order --, bucket 0 reads as [0, 2 n0) and bucket 1 starts at 2 n0.  That layout is built here, place by place,
+// from the plain sorted records (rec_tmp) into the persistent array for a stream with n0 > 0 (black areas in
+// full-range content); the walk then scans whole buckets by these rules (walk_buckets).  The index kol2 keeps
+// describing the plain sorted order.
+__global__ __launch_bounds__(256) void k_sort_quirk(FerDev d, const uint32_t *rec_tmp)
 {
-    __shared__ unsigned h[256];
-    const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;
+    const int n0 = d.zero_cnt[s];
+    if (n0 == 0) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;  // place of the final array
     const int n = d.W * d.H;
-    keys += (size_t)s * n;
-    h[tid] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < RS_ITEMS; i++) {
-        int idx = tile * RS_TILE + i * RS_THREADS + tid;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 0xff], 1u);
+    if (p >= n) return;
+    const size_t g0 = (size_t)s * n;
+    const int ir = p + n0;   // the regular position that lands here (sorted index), if any
+    const int iz = p - n0;   // the sum-0 position aimed here, if any
+    const bool hr = ir < n, hz = iz >= 0 && iz < n0;
+    int src = -1;
+    if (hr && hz) {
+        const uint32_t vr = d.sort_pos[g0 + ir], vz = d.sort_pos[g0 + iz];
+        const int br = (int)(vr >> 16) * d.H + (int)(vr & 0xffff), bz = (int)(vz >> 16) * d.H + (int)(vz & 0xffff);
+        src = bz > br ? iz : ir;
+    } else if (hr) {
+        src = ir;
+    } else if (hz) {
+        src = iz;
     }
-    __syncthreads();
-    hist[((size_t)s * 256 + tid) * ntiles + tile] = h[tid];  // digit-major: the scan order is the output order
-}
-
-__global__ __launch_bounds__(256) void k_rs_scan(FerDev d, uint32_t *hist, int ntiles)
-{
-    __shared__ unsigned part[256];
-    const int s = blockIdx.x, tid = threadIdx.x;
-    if (d.hdr[s * 4 + 3] != 0) return;
-    uint32_t *h = hist + (size_t)s * 256 * ntiles;
-    const int n = 256 * ntiles;
-    const int per = (n + 255) / 256;
-    const int b0 = min(tid * per, n), b1 = min(b0 + per, n);
-    unsigned sum = 0;
-    for (int i = b0; i < b1; i++) sum += h[i];
-    part[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        unsigned v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    unsigned run = tid ? part[tid - 1] : 0;
-    for (int i = b0; i < b1; i++) {
-        unsigned v = h[i];
-        h[i] = run;
-        run += v;
-    }
-}
-
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint32_t *keys_in, const uint32_t *vals_in,
-                                                          uint32_t *keys_out, uint32_t *vals_out, const uint32_t *hist,
-                                                          int ntiles, int shift)
-{
-    __shared__ unsigned run[RS_THREADS / 64][256];  // per wavefront: items of each digit seen so far
-    __shared__ unsigned base[256];
-    const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    if (d.hdr[s * 4 + 3] != 0) return;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int n = d.W * d.H;
-    keys_in += (size_t)s * n;
-    vals_in += (size_t)s * n;
-    keys_out += (size_t)s * n;
-    vals_out += (size_t)s * n;
-#pragma unroll
-    for (int w = 0; w < RS_THREADS / 64; w++) run[w][tid] = 0;
-    base[tid] = hist[((size_t)s * 256 + tid) * ntiles + tile];
-    __syncthreads();
-    // a wavefront owns a contiguous quarter of the tile and walks it in arrival order, 64 items per round
-    const int w0 = tile * RS_TILE + wv * (RS_TILE / (RS_THREADS / 64));
-    uint32_t key[RS_ITEMS], val[RS_ITEMS];
-    unsigned rk[RS_ITEMS];  // rank among the wavefront's earlier items of the same digit
-    const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        int idx = w0 + r * 64 + lane;
-        bool ok = idx < n;
-        key[r] = ok ? keys_in[idx] : 0xffffffffu;
-        val[r] = ok ? vals_in[idx] : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        const bool ok = w0 + r * 64 + lane < n;
-        const unsigned dg = (key[r] >> shift) & 0xff;
-        unsigned long long peers = __ballot(ok);  // lanes with the same digit
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            unsigned long long bal = __ballot((dg >> b) & 1);
-            peers &= ((dg >> b) & 1) ? bal : ~bal;
-        }
-        const unsigned before = run[wv][dg];
-        rk[r] = before + (unsigned)__popcll(peers & lt);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (ok && (peers & lt) == 0) run[wv][dg] = before + (unsigned)__popcll(peers);  // first lane of the group
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    // The tile is first put in output order inside LDS (digit runs one after the other), then written out: a
-    // thread's neighbours write neighbouring addresses of the same digit run instead of 256 scattered streams.
-    __shared__ unsigned dstart[256];
-    __shared__ uint32_t sk[RS_TILE], sv[RS_TILE];
-    unsigned tot = 0;
-    {  // digit tid: wavefront totals -> offsets inside the digit's run of this tile
-#pragma unroll
-        for (int w = 0; w < RS_THREADS / 64; w++) {
-            unsigned c = run[w][tid];
-            run[w][tid] = tot;
-            tot += c;
-        }
-    }
-    {  // exclusive prefix of the tile's digit totals (256 values, one per thread)
-        unsigned inc = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            unsigned v = __shfl_up(inc, o);
-            if (lane >= o) inc += v;
-        }
-        __shared__ unsigned wsum[RS_THREADS / 64];
-        if (lane == 63) wsum[wv] = inc;
-        __syncthreads();
-        unsigned before = 0;
-        for (int w = 0; w < wv; w++) before += wsum[w];
-        dstart[tid] = before + inc - tot;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        if (w0 + r * 64 + lane < n) {
-            const unsigned dg = (key[r] >> shift) & 0xff;
-            const unsigned lp = dstart[dg] + run[wv][dg] + rk[r];
-            sk[lp] = key[r];
-            sv[lp] = val[r];
-        }
-    }
-    __syncthreads();
-    const int cnt = min(RS_TILE, n - tile * RS_TILE);
-    for (int i = tid; i < cnt; i += RS_THREADS) {
-        const uint32_t k = sk[i];
-        const unsigned dg = (k >> shift) & 0xff;
-        const unsigned pos = base[dg] + ((unsigned)i - dstart[dg]);
-        keys_out[pos] = k;
-        vals_out[pos] = sv[i];
-    }
+    if (src < 0) return;  // keeps the previous picture's entry
+    const uint32_t *in = rec_tmp + (g0 + src) * 3;
+    uint32_t *o = d.sort_rec + (g0 + p) * 3;
+    o[0] = in[0];
+    o[1] = in[1];
+    o[2] = in[2];
 }
 
 size_t fer_sort_tmp_bytes(int n, int S)
 {
     const int ntiles = (n + RS_TILE - 1) / RS_TILE;
-    return (size_t)S * 256 * ntiles * sizeof(uint32_t);
+    return (size_t)S * RS_ND * ntiles * sizeof(uint32_t);
 }
 
-// host side: prepare the reference structures of all P-picture streams (three profiled steps)
+// host side: prepare the reference structures of all P-picture streams (profiled steps)
 void fer_launch_interp(const FerDev &d, hipStream_t st)
 {
     dim3 gi((d.W + IT_W - 1) / IT_W, (d.H + IT_H - 1) / IT_H, d.S);
@@ -440,39 +529,33 @@ void fer_launch_features(const FerDev &d, hipStream_t st)
     hipLaunchKernelGGL(k_features, dim3((unsigned)((fw + 3) / 4)), dim3(256), 0, st, d);
 }
 
-// the sort in three profiled steps: keys, the two radix passes, payload + bucket index
+// plane-0 features + the sort input (profiled as "sort_keys")
 void fer_launch_sort_keys(const FerDev &d, FerSortTmp &t, hipStream_t st)
 {
-    int n = d.W * d.H;
     hipMemsetAsync(d.zero_cnt, 0, sizeof(int) * d.S, st);
-    hipLaunchKernelGGL(k_sort_keys, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.keys_in, t.vals_in);
+    dim3 g((d.W + F0_T - 1) / F0_T, (d.H + F0_T - 1) / F0_T, d.S);
+    hipLaunchKernelGGL(k_feat0, g, dim3(256), 0, st, d, t.recT, t.keyT);
 }
 
 void fer_launch_sort_radix(const FerDev &d, FerSortTmp &t, hipStream_t st)
 {
-    int n = d.W * d.H;
+    const int n = d.W * d.H;
     const int ntiles = (n + RS_TILE - 1) / RS_TILE;
     uint32_t *hist = (uint32_t *)t.tmp;
-    uint32_t *ki = t.keys_in, *vi = t.vals_in, *ko = t.keys_out, *vo = t.vals_out;
-    for (int pass = 0; pass < 2; pass++) {  // sum bits 0-7, then 8-14
-        const int shift = pass * 8;
-        hipLaunchKernelGGL(k_rs_hist, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, ki, hist, ntiles, shift);
+    for (int pass = 0; pass < 2; pass++) {  // sum bits 0-6, then 7-13
+        hipLaunchKernelGGL(k_rs_hist, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, t.keyT, t.dig2, hist, ntiles, pass);
         hipLaunchKernelGGL(k_rs_scan, dim3(d.S), dim3(256), 0, st, d, hist, ntiles);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, ki, vi, ko, vo, hist, ntiles, shift);
-        uint32_t *x = ki;
-        ki = ko;
-        ko = x;
-        x = vi;
-        vi = vo;
-        vo = x;
+        hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, t.keyT, t.dig2, pass == 0 ? t.recT : t.rec1, t.rec1,
+                           t.dig2, t.rec_tmp, t.skey, hist, ntiles, pass);
     }
 }
 
+// bucket index (+ the reference's mis-filed layout for streams with sum-0 positions)
 void fer_launch_sort_finish(const FerDev &d, FerSortTmp &t, hipStream_t st)
 {
-    int n = d.W * d.H;
-    // after two passes the sorted pairs are back in keys_in / vals_in
-    hipLaunchKernelGGL(k_sort_finish, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.keys_in, t.vals_in);
+    const int n = d.W * d.H;
+    hipLaunchKernelGGL(k_sort_index, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
+    hipLaunchKernelGGL(k_sort_quirk, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.rec_tmp);
 }
 
 void fer_launch_sort(const FerDev &d, FerSortTmp &t, hipStream_t st)

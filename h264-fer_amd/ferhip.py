@@ -72,6 +72,7 @@ def load_library():
     lib.ferhip_read_buffer.argtypes = [vp, i, vp, sz]
     lib.ferhip_read_buffer.restype = sz
     lib.ferhip_profile.argtypes = [vp, i]
+    lib.ferhip_tune.argtypes = [vp, i, i]
     lib.ferhip_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), i]
     lib.ferhip_decode_streams.argtypes = [C.POINTER(C.c_char_p), C.POINTER(sz), i, vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     lib.ferhip_decode_release.argtypes = []
@@ -264,6 +265,9 @@ class FerHip:
     PHASES = ("interp", "me_pre", "me_resolve", "p_resid", "intra", "cavlc", "frame_sad", "features", "sort", "me_walk",
               "sort_keys", "sort_finish")
     NPHASE = 12
+
+    def tune(self, key, value):
+        _chk(self.lib.ferhip_tune(self.ctx, key, value), "ferhip_tune")
 
     def profile(self, enable=True):
         _chk(self.lib.ferhip_profile(self.ctx, int(enable)), "ferhip_profile")

@@ -134,6 +134,11 @@ const char *ferhip_version(void);
 #define FERHIP_PH_SORT_FINISH 11 /* k_sort_finish: payload of the sorted order + bucket index */
 #define FERHIP_NPHASE 12
 int ferhip_profile(ferhip_ctx *c, int enable);
+/* launch-shape knobs; results never depend on them.  RESOLVE_WGS = workgroups of the persistent motion-chain launch
+ * (default 1536: leaves CU slots to a second context; a context that has the GPU to itself can take more) */
+#define FERHIP_TUNE_RESOLVE_WGS 1
+#define FERHIP_TUNE_RESOLVE_GROUP 2 /* streams whose rows the motion chain keeps in flight together (cache footprint) */
+int ferhip_tune(ferhip_ctx *c, int key, int value);
 int ferhip_get_profile(ferhip_ctx *c, double *ms, long *launches, int reset);
 
 /* ---- per-stage entry points (unit-parity surface, SURVEY.md 8b "per-MB") ----
