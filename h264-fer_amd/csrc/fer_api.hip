@@ -209,7 +209,10 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     int rc = 0;
     rc |= dalloc(c, &c->planes[0], fsz * S);
     rc |= dalloc(c, &c->planes[1], fsz * S);
-    rc |= dalloc(c, &d.interp, decode_only ? (size_t)1 : (size_t)(d.ysz * 16 * S));
+    d.ipitch = W + FER_IP_L + FER_IP_R;
+    d.iplane = (((size_t)d.ipitch * (H + FER_IP_T + FER_IP_B)) + 255) & ~(size_t)255;
+    d.ioff = FER_IP_T * d.ipitch + FER_IP_L;
+    rc |= dalloc(c, &d.interp, decode_only ? (size_t)1 : (size_t)(d.iplane * 16 * S));
     rc |= dalloc(c, &d.feat, decode_only ? (size_t)1 : (size_t)(d.ysz * 96 * S));
     rc |= dalloc(c, &d.feat0, decode_only ? (size_t)1 : (size_t)(d.ysz * 6 * S));
     rc |= dalloc(c, &d.sort_pos, decode_only ? (size_t)1 : (size_t)(d.ysz * S));
@@ -1013,7 +1016,15 @@ extern "C" size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t
     const void *src = nullptr;
     size_t n = 0;
     switch (which) {
-    case FERHIP_BUF_INTERP: src = d.interp; n = d.ysz * 16 * d.S; break;
+    case FERHIP_BUF_INTERP: {  // the planes without their margins
+        n = d.ysz * 16 * d.S;
+        if (n > cap) return 0;
+        for (int pl = 0; pl < 16 * d.S; pl++)
+            if (hipMemcpy2D((uint8_t *)dst + (size_t)pl * d.ysz, (size_t)d.W, d.interp + (size_t)pl * d.iplane + d.ioff, (size_t)d.ipitch,
+                            (size_t)d.W, (size_t)d.H, hipMemcpyDeviceToHost) != hipSuccess)
+                return 0;
+        return n;
+    }
     case FERHIP_BUF_FEAT: src = d.feat; n = d.ysz * 96 * d.S * 2; break;
     case FERHIP_BUF_SORTPOS: src = d.sort_pos; n = d.ysz * d.S * 4; break;
     case FERHIP_BUF_KOLIKO: {  // the reference's koliko[] = first level of the bucket index, relative to the stream's segment

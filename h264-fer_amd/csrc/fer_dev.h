@@ -23,6 +23,10 @@
 #define FER_P_SKIP 31
 #define FER_MV_NA ((int)0x80808080u)
 
+#define FER_IP_L 16  // margins of the interpolated planes: left / right / top / bottom
+#define FER_IP_R 16
+#define FER_IP_T 4
+#define FER_IP_B 12
 #define FER_ST2_CAP 384  // stage-2 candidates kept per 8x8 partition
 #define FER_LEVELS 400   // int16 per MB: luma 16x16, dc16 16, cdc 2x4, cac 2x4x15
 #define FER_LV_DC16 256
@@ -39,7 +43,13 @@ struct FerDev {
     uint8_t *curY, *curCb, *curCr;
     uint8_t *refY, *refCb, *refCr;
     // a16: 16 quarter-pel planes, 5 box features per plane, positions sorted by 8x8 sum
-    uint8_t *interp;     // [S][16][H][W]
+    // 16 quarter-pel planes of the reference luma, each with a replicated margin (FER_IP_* pixels): a block that
+    // hangs over the right / bottom picture edge reads what the reference's per-sample clamp (F/moestimation.cpp:
+    // 107-115,189-190) would give without any clamp, and 16-byte row loads around any valid position stay inside
+    // the plane.  Pixel (x, y) of plane f of stream s: interp + (s * 16 + f) * iplane + ioff + y * ipitch + x.
+    uint8_t *interp;
+    int ipitch, ioff;
+    size_t iplane;
     uint16_t *feat;      // [S][H][W][16][6]  k0..k4 + pad per (position, frac): one 12-byte load per candidate
     uint16_t *feat0;     // [S][H][W][6]      plane-0 copy for the wide integer search
     uint32_t *sort_pos;  // [S][W*H]  (tx << 16) | ty, ordered by (sum, tx, ty)
@@ -445,12 +455,25 @@ __device__ __forceinline__ void load_u8x8(const uint8_t *__restrict__ p, uint32_
 // luma prediction of 4 consecutive samples (x..x+3, y) of the MB at (xP,yP): when every target
 // position lies inside the picture the motion-compensated value IS the interpolated plane
 // (identical clamped taps), read as packed bytes; otherwise the exact per-sample path.
-__device__ __forceinline__ void mc_luma4(const uint8_t *__restrict__ R, const uint8_t *__restrict__ Ps, size_t ysz,
-                                         int W, int H, int xP, int yP, int x, int y, int mvx, int mvy, int out[4])
+struct IPlanes {  // the 16 interpolated planes of one stream
+    const uint8_t *base;  // pixel (0, 0) of plane 0
+    int pitch;
+    size_t plane;
+};
+__device__ __forceinline__ IPlanes ip_stream(const FerDev &d, int s)
+{
+    IPlanes ip;
+    ip.base = d.interp + (size_t)s * 16 * d.iplane + d.ioff;
+    ip.pitch = d.ipitch;
+    ip.plane = d.iplane;
+    return ip;
+}
+__device__ __forceinline__ void mc_luma4(const uint8_t *__restrict__ R, const IPlanes &ip, int W, int H, int xP, int yP, int x,
+                                         int y, int mvx, int mvy, int out[4])
 {
     int X = xP + x + (mvx >> 2), Y = yP + y + (mvy >> 2);
     if (X >= 0 && X + 3 < W && Y >= 0 && Y < H) {
-        uint32_t v = load_u8x4(Ps + (size_t)((mvy & 3) * 4 + (mvx & 3)) * ysz + (size_t)Y * W + X);
+        uint32_t v = load_u8x4(ip.base + (size_t)((mvy & 3) * 4 + (mvx & 3)) * ip.plane + (size_t)Y * ip.pitch + X);
         out[0] = v & 0xff;
         out[1] = (v >> 8) & 0xff;
         out[2] = (v >> 16) & 0xff;

@@ -306,59 +306,11 @@ __device__ __forceinline__ FeatRec feat0_load(const uint16_t *__restrict__ F0, i
     return f;
 }
 
-// SAD of the 8x8 source block against interpolated plane (F/moestimation.cpp:175-195).
-// 8 lanes (rows) per candidate, 8 candidates per call: lane = cand*8 + row; src = the lane's
-// source row packed in two dwords.  Split into an unconditional load (three aligned dwords that
-// cover the 8 reference samples; a row that runs over the right picture edge reads into the
-// next row, which stays inside the allocation) and the reduction, so that a caller can have the
-// loads of all its rounds in flight before the first reduction.
-struct SadRow {
-    uint32_t w0, w1, w2;
-    int sh, nv;  // byte offset of the first sample in w0; samples left of the right picture edge
-};
-__device__ __forceinline__ SadRow sad_row_load(const uint8_t *__restrict__ Ps, size_t ysz, int W, int H, int xP, int yP,
-                                               int mvx, int mvy, int row)
-{
-    int xPi = iclamp(xP + (mvx >> 2), 0, W - 1), yPi = iclamp(yP + (mvy >> 2), 0, H - 1);
-    const uint8_t *p = Ps + (size_t)((mvx & 3) + (mvy & 3) * 4) * ysz + (size_t)min(yPi + row, H - 1) * W + xPi;
-    const uint32_t *a = (const uint32_t *)(p - ((uintptr_t)p & 3));  // pointer arithmetic keeps the global address space
-    SadRow r;
-    r.w0 = a[0];
-    r.w1 = a[1];
-    r.w2 = a[2];
-    r.sh = (int)((uintptr_t)p & 3);
-    r.nv = W - xPi;
-    return r;
-}
-// returns the full SAD in every lane of the 8-lane group
-__device__ __forceinline__ int sad_row_reduce(const SadRow &r, uint32_t s0, uint32_t s1)
-{
-    uint32_t r0 = __builtin_amdgcn_alignbyte(r.w1, r.w0, (uint32_t)r.sh);
-    uint32_t r1 = __builtin_amdgcn_alignbyte(r.w2, r.w1, (uint32_t)r.sh);
-    if (__any(r.nv < 8)) {  // right edge: the reference clamps each column (F/moestimation.cpp:189)
-        if (r.nv < 8) {
-            unsigned long long v = ((unsigned long long)r1 << 32) | r0;
-            unsigned long long last = (v >> (8 * (r.nv - 1))) & 0xffull;
-            unsigned long long keep = (1ull << (8 * r.nv)) - 1ull;
-            v = (v & keep) | ((last * 0x0101010101010101ull) & ~keep);
-            r0 = (uint32_t)v;
-            r1 = (uint32_t)(v >> 32);
-        }
-    }
-    int s = (int)__builtin_amdgcn_sad_u8(r1, s1, __builtin_amdgcn_sad_u8(r0, s0, 0));
-    return oct_sum(s);
-}
-__device__ __forceinline__ int sad8_rows(const uint8_t *__restrict__ Ps, size_t ysz, int W, int H, int xP, int yP,
-                                         int mvx, int mvy, int row, uint32_t s0, uint32_t s1)
-{
-    SadRow r = sad_row_load(Ps, ysz, W, H, xP, yP, mvx, mvy, row);
-    return sad_row_reduce(r, s0, s1);
-}
-
-// The same SAD, ONE CANDIDATE PER LANE: the lane walks the eight rows of the block at its own vector; the source
-// block is wave-uniform (scalar registers), so nothing crosses lanes.  Eight lanes per candidate (above) cost a
-// round of address arithmetic, loads and a cross-lane reduction per 8 candidates; a list of 17 or 33 candidates
-// is one pass here.
+// SAD of the 8x8 source block against the interpolated plane at the lane's OWN vector (satdLuma8x8MVs,
+// F/moestimation.cpp:175-195), ONE CANDIDATE PER LANE: the lane walks the eight rows of the block; the source block
+// is wave-uniform (scalar registers), so nothing crosses lanes, and a list of 17 or 33 candidates is one pass.  The
+// block origin is clamped into the picture (the reference shifts the block at the left / top edges, :181-182); rows
+// and columns beyond the right / bottom edge come from the planes' replicated margin (= the per-sample clamp :189-190).
 struct SrcBlk {
     uint32_t lo[8], hi[8];
 };
@@ -373,42 +325,24 @@ __device__ __forceinline__ SrcBlk src_block_load(const uint8_t *__restrict__ Y, 
     }
     return b;
 }
-__device__ __forceinline__ int sad_lane(const uint8_t *__restrict__ Ps, size_t ysz, int W, int H, int sx, int sy, int mvx, int mvy,
-                                        const SrcBlk &S)
+__device__ __forceinline__ int sad_lane(const IPlanes &ip, int W, int H, int sx, int sy, int mvx, int mvy, const SrcBlk &S)
 {
     const int xPi = iclamp(sx + (mvx >> 2), 0, W - 1), yPi = iclamp(sy + (mvy >> 2), 0, H - 1);
     const uint32_t sh = (uint32_t)(xPi & 3);  // planes and rows start on 16-byte boundaries
-    const uint8_t *p0 = Ps + (size_t)((mvx & 3) + (mvy & 3) * 4) * ysz + (xPi & ~3);
-    const int nv = W - xPi;
+    const uint8_t *p0 = ip.base + (size_t)((mvx & 3) + (mvy & 3) * 4) * ip.plane + (size_t)yPi * ip.pitch + (xPi & ~3);
     uint32_t w[8][3];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const uint32_t *a = (const uint32_t *)(p0 + (size_t)min(yPi + r, H - 1) * W);
+        const uint32_t *a = (const uint32_t *)(p0 + (size_t)r * ip.pitch);
         w[r][0] = a[0];
         w[r][1] = a[1];
         w[r][2] = a[2];
     }
     uint32_t sad = 0;
-    if (__any(nv < 8)) {  // right edge: the reference clamps each column (F/moestimation.cpp:189)
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            uint32_t r0 = __builtin_amdgcn_alignbyte(w[r][1], w[r][0], sh), r1 = __builtin_amdgcn_alignbyte(w[r][2], w[r][1], sh);
-            if (nv < 8) {
-                unsigned long long v = ((unsigned long long)r1 << 32) | r0;
-                unsigned long long last = (v >> (8 * (nv - 1))) & 0xffull;
-                unsigned long long keep = (1ull << (8 * nv)) - 1ull;
-                v = (v & keep) | ((last * 0x0101010101010101ull) & ~keep);
-                r0 = (uint32_t)v;
-                r1 = (uint32_t)(v >> 32);
-            }
-            sad = __builtin_amdgcn_sad_u8(r1, S.hi[r], __builtin_amdgcn_sad_u8(r0, S.lo[r], sad));
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint32_t r0 = __builtin_amdgcn_alignbyte(w[r][1], w[r][0], sh), r1 = __builtin_amdgcn_alignbyte(w[r][2], w[r][1], sh);
-            sad = __builtin_amdgcn_sad_u8(r1, S.hi[r], __builtin_amdgcn_sad_u8(r0, S.lo[r], sad));
-        }
+    for (int r = 0; r < 8; r++) {
+        const uint32_t r0 = __builtin_amdgcn_alignbyte(w[r][1], w[r][0], sh), r1 = __builtin_amdgcn_alignbyte(w[r][2], w[r][1], sh);
+        sad = __builtin_amdgcn_sad_u8(r1, S.hi[r], __builtin_amdgcn_sad_u8(r0, S.lo[r], sad));
     }
     return (int)sad;
 }
@@ -432,7 +366,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     const int W = d.W, H = d.H;
     const size_t ysz = d.ysz;
     const uint8_t *Y = d.curY + (size_t)s * ysz;
-    const uint8_t *Ps = d.interp + (size_t)s * 16 * ysz;
+    const IPlanes ip = ip_stream(d, s);
     const uint16_t *Fs = d.feat + (size_t)s * 96 * ysz;
     const int sx = ((mb % d.mbw) << 4) + (part & 1) * 8, sy = ((mb / d.mbw) << 4) + (part >> 1) * 8;
     const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
@@ -597,7 +531,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     if (!FER_DBGF(d, 4)) {  // SADs of the survivors: list slot j lives in lane j
         const SrcBlk SB = src_block_load(Y, W, sx, sy);
         const int cx = unp_x(L.xy), cy = unp_y(L.xy);
-        const int sad = sad_lane(Ps, ysz, W, H, sx, sy, lane < n3 ? cx : 0, lane < n3 ? cy : 0, SB);
+        const int sad = sad_lane(ip, W, H, sx, sy, lane < n3 ? cx : 0, lane < n3 ? cy : 0, SB);
         if (lane < n3) {
             int *o = d.st3 + (pidx * 33 + lane) * 3;
             o[0] = cx;
@@ -613,14 +547,21 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
 // The bucket walk of F/moestimation.cpp:470-496.  For j = 0, 1, ... the buckets su[0]-j and su[0]+j are scanned in
 // (tx, ty) order; a candidate passes when it is inside the 280-diamond and its two half sums are within 100; the
 // walk stops after the j that takes the count past 128 (bucket su[0] is visited twice at j = 0, like the
-// reference).  Buckets are entered through the column-tile index, so only the slice whose tx can pass is read,
-// and the slices are cut into 64-entry batches that are fetched two ahead of the one being filtered (each
+// reference).  Buckets are entered through the column-tile index, so only the slice whose tx can pass is read (each
 // record is one 12-byte load; the exact filter decides, so the candidate set and its order are the reference's).
+//
+// Control flow is kept off the scalar unit (one per CU: a state machine that produced the next 64-record batch with
+// ~30 scalar instructions made this kernel scalar-issue bound).  The slices of 16 steps j (32 slices) are cut into
+// batches by the LANES: slice k lives in lane k, an exclusive prefix of the batch counts places its batches in a
+// table in LDS, and lane b then holds the descriptor of batch b: first record, record count, bucket, "last batch of
+// its step" (where the stop test falls).  The batch loop reads descriptors with v_readlane, two batches in flight.
+// Groups of steps with more than 64 batches (flat content: thousands of positions per sum) go slice by slice.
 // sink(ok, rank, rel, D) is called for every batch by all lanes: ok = the lane holds a candidate, rank = its
 // arrival index, rel = (tx - sx) << 16 | (ty - sy) & 0xffff, D = its feature distance.  Returns the count.
+// tbl = 128 dwords of LDS private to the calling wavefront.
 template <class SINK>
 __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&su)[5], const SuPk &sp, int sx, int sy, int lane,
-                                            SINK sink)
+                                            uint32_t *tbl, SINK sink)
 {
     int tren = 0;
     if (d.basic || FER_DBGF(d, 8)) return 0;
@@ -628,7 +569,7 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
     const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * kt;
     const uint32_t *srec = d.sort_rec;  // indexed by the device-wide positions kol2 holds
     // A stream whose reference picture has n0 > 0 positions of sum 0 carries the reference's mis-filed bucket layout
-    // (k_sort_finish): whole buckets are scanned by its rules -- bucket 0 = [0, 2 n0), bucket 1 from 2 n0, the others
+    // (k_sort_quirk): whole buckets are scanned by its rules -- bucket 0 = [0, 2 n0), bucket 1 from 2 n0, the others
     // n0 places early, the last one up to the end of the array --, and a record may sit in a bucket it does not
     // belong to (or be left over from the previous picture), so its distance is taken from the features at its
     // position, as the reference does, not from the record.
@@ -643,66 +584,14 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
         if (a >= 16384) return g0 + npos;
         return kol2[(size_t)a * kt] - (uint32_t)n0;
     };
-    // slice generator state (wave-uniform): bounds of 64 steps j on both sides live one per lane
-    int jn = 0, side = 0;             // next slice to open
-    unsigned cur = 0, end = 0;        // rest of the open slice
-    int cur_a = 0, cur_last = 0;      // its bucket; 1 = second side of its j (the stop test follows it)
-    unsigned kb = 0;                  // bucket bounds of 16 steps, see gen
-    bool open = false, done = false;
-    // next batch: start index, entry count (0 = nothing to read), bucket, flags (1 = stop test after it, 2 = end of walk)
-    auto gen = [&](unsigned &b_start, int &b_cnt, int &b_a, int &b_flags) {
-        b_start = 0;
-        b_cnt = 0;
-        b_a = 0;
-        b_flags = 0;
-        if (done) {
-            b_flags = 2;
-            return;
-        }
-        if (!open) {
-            if (jn > 180) {
-                done = true;
-                b_flags = 2;
-                return;
-            }
-            if (side == 0 && (jn & 15) == 0) {
-                // bucket bounds of the next 16 steps in ONE gather: lane = which * 16 + step, which = 0 / 1 first and
-                // end of the low side's slice, 2 / 3 of the high side's (most walks end within a few steps)
-                const int which = lane >> 4, jj = jn + (lane & 15);
-                const int a = (which & 2) ? su[0] + jj : su[0] - jj;
-                const bool va = a >= 0 && a < 16384;
-                unsigned v = 0u;
-                if (!quirk) {
-                    if (va) v = kol2[(size_t)a * kt + ((which & 1) ? t_hi + 1 : t_lo)];
-                } else {
-                    if (va) v = qstart(a + (which & 1));
-                }
-                kb = v;
-            }
-            cur = (unsigned)lane_bcast((int)kb, (jn & 15) + (side ? 32 : 0));
-            end = (unsigned)lane_bcast((int)kb, (jn & 15) + (side ? 48 : 16));
-            cur_a = side ? su[0] + jn : su[0] - jn;
-            cur_last = side;
-            open = true;
-            if (side) jn++;
-            side ^= 1;
-        }
-        b_start = cur;
-        b_cnt = end > cur ? (int)min(end - cur, 64u) : 0;
-        b_a = cur_a;
-        cur += 64;
-        if (cur >= end) {
-            open = false;
-            b_flags = cur_last;
-        }
-    };
+    const uint32_t sxy = ((uint32_t)sx << 16) | (uint32_t)sy;  // the records' (tx << 16) | ty pairing
+    // descriptor of a batch: start record; count (bits 0-6) | last-of-step (bit 7) | bucket << 8
     auto fetch = [&](unsigned b_start, int b_cnt, uint32_t &r0, uint32_t &r1, uint32_t &r2) {
         const uint32_t *e = srec + (size_t)(b_start + (unsigned)min(lane, max(b_cnt - 1, 0))) * 3;
         r0 = e[0];
         r1 = e[1];
         r2 = e[2];
     };
-    const uint32_t sxy = ((uint32_t)sx << 16) | (uint32_t)sy;  // the records' (tx << 16) | ty pairing
     auto filter = [&](int b_cnt, int a, uint32_t r0, uint32_t r1, uint32_t r2) {
         // |tx - sx| + |ty - sy| < 280 and both half sums within 100, on u16 pairs
         uint32_t dist = __builtin_amdgcn_sad_u16(r0, sxy, 0);
@@ -725,24 +614,95 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
         sink(ok, rank, (int)pk_sub16(r0, sxy), (int)D);
         tren += __popcll(mk);
     };
-    unsigned sA, sB;
-    int cA, cB, aA, aB, fA, fB;
-    uint32_t A0, A1, A2, B0, B1, B2;
-    gen(sA, cA, aA, fA);
-    fetch(sA, cA, A0, A1, A2);
-    gen(sB, cB, aB, fB);
-    fetch(sB, cB, B0, B1, B2);
-    for (;;) {  // two batches in flight, no register copies between them
-        if (fA & 2) break;
-        filter(cA, aA, A0, A1, A2);
-        if ((fA & 1) && tren > 128) break;
-        gen(sA, cA, aA, fA);
+    // runs the nb <= 64 batches whose descriptors sit one per lane; true = the walk is over
+    auto run_table = [&](uint32_t dstart, uint32_t dinfo, int nb) -> bool {
+        auto desc = [&](int b, unsigned &bs, int &bc, int &ba, int &bl) {
+            const int bb = min(b, 63);
+            const uint32_t st_ = (uint32_t)__builtin_amdgcn_readlane((int)dstart, bb), in_ = (uint32_t)__builtin_amdgcn_readlane((int)dinfo, bb);
+            bs = b < nb ? st_ : g0;
+            bc = b < nb ? (int)(in_ & 127u) : 0;
+            ba = (int)(in_ >> 8);
+            bl = b < nb ? (int)((in_ >> 7) & 1u) : 0;
+        };
+        unsigned sA, sB;
+        int cA, cB, aA, aB, lA, lB;
+        uint32_t A0, A1, A2, B0, B1, B2;
+        desc(0, sA, cA, aA, lA);
         fetch(sA, cA, A0, A1, A2);
-        if (fB & 2) break;
-        filter(cB, aB, B0, B1, B2);
-        if ((fB & 1) && tren > 128) break;
-        gen(sB, cB, aB, fB);
+        desc(1, sB, cB, aB, lB);
         fetch(sB, cB, B0, B1, B2);
+        for (int b = 0; b < nb; b += 2) {  // two batches in flight, no register copies between them
+            filter(cA, aA, A0, A1, A2);
+            if (lA && tren > 128) return true;
+            desc(b + 2, sA, cA, aA, lA);
+            fetch(sA, cA, A0, A1, A2);
+            if (b + 1 >= nb) break;
+            filter(cB, aB, B0, B1, B2);
+            if (lB && tren > 128) return true;
+            desc(b + 3, sB, cB, aB, lB);
+            fetch(sB, cB, B0, B1, B2);
+        }
+        return false;
+    };
+    for (int j0 = 0; j0 <= 180; j0 += 16) {
+        // bucket bounds of 16 steps in ONE gather: lane = which * 16 + step, which = 0 / 1 first and end of the low
+        // side's slice, 2 / 3 of the high side's
+        uint32_t kb = 0u;
+        {
+            const int which = lane >> 4, jj = j0 + (lane & 15);
+            const int a = (which & 2) ? su[0] + jj : su[0] - jj;
+            const bool va = a >= 0 && a < 16384 && jj <= 180;
+            if (!quirk) {
+                if (va) kb = kol2[(size_t)a * kt + ((which & 1) ? t_hi + 1 : t_lo)];
+            } else {
+                if (va) kb = qstart(a + (which & 1));
+            }
+        }
+        // slice k = step * 2 + side in lane k < 32
+        const int step = (lane >> 1) & 15, side = lane & 1;
+        const uint32_t st = (uint32_t)__shfl((int)kb, step + (side ? 32 : 0)), en = (uint32_t)__shfl((int)kb, step + (side ? 48 : 16));
+        const uint32_t cnt = (lane < 32 && en > st) ? en - st : 0u;
+        const int nb = (int)((cnt + 63u) >> 6);
+        const int a_k = side ? su[0] + j0 + step : su[0] - (j0 + step);
+        int pre = nb;  // inclusive prefix over the lanes
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            int v = __shfl_up(pre, o);
+            if (lane >= o) pre += v;
+        }
+        const int TB = __builtin_amdgcn_readlane(pre, 31);
+        if (TB == 0) continue;
+        if (TB <= 64) {
+            // the step's last batch: the high side's last one, or the low side's when the high side is empty
+            const int nb_hi = __shfl(nb, lane | 1);
+            const bool closes = side == 1 || nb_hi == 0;
+            for (int i = 0; __any(i < nb); i++) {
+                if (i < nb) {
+                    const int b = pre - nb + i;
+                    const uint32_t c = min(cnt - 64u * (uint32_t)i, 64u);
+                    tbl[b] = st + 64u * (uint32_t)i;
+                    tbl[64 + b] = c | ((closes && i == nb - 1) ? 128u : 0u) | ((uint32_t)a_k << 8);
+                }
+            }
+            WAVE_LDS_SYNC();
+            const uint32_t dstart = tbl[lane], dinfo = tbl[64 + lane];
+            WAVE_LDS_SYNC();
+            if (run_table(dstart, dinfo, TB)) return tren;
+        } else {
+            // a crowded group: slice by slice, 64 batches of a slice at a time
+            for (int k = 0; k < 32; k++) {
+                const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)st, k), kc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, k);
+                const int ka = __builtin_amdgcn_readlane(a_k, k);
+                const int knb = (int)((kc + 63u) >> 6);
+                for (int b0 = 0; b0 < knb; b0 += 64) {
+                    const int m = min(64, knb - b0);
+                    const uint32_t off = 64u * (uint32_t)(b0 + lane);
+                    const uint32_t c = lane < m ? min(kc - off, 64u) : 0u;
+                    if (run_table(ks + off, c | ((uint32_t)ka << 8), m)) return tren;  // stop tests fall between steps only
+                }
+                if ((k & 1) && tren > 128) return tren;
+            }
+        }
     }
     return tren;
 }
@@ -776,7 +736,8 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
     su[4] = wave_sum((px & 3) > 1 ? 0 : v);
     const SuPk sp = su_pack(su);
     int2 *out = (int2 *)(d.st2 + pidx * FER_ST2_CAP * 2);
-    const int tren = walk_buckets(d, s, su, sp, sx, sy, lane, [&](bool ok, int rank, int rel, int D) {
+    __shared__ uint32_t tbl[128];
+    const int tren = walk_buckets(d, s, su, sp, sx, sy, lane, tbl, [&](bool ok, int rank, int rel, int D) {
         if (ok && rank < FER_ST2_CAP) out[rank] = make_int2(rel, D);
     });
     if (lane == 0) d.st2n[pidx] = tren;
@@ -785,13 +746,12 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
 // SAD of the K list entries (slot j in lane j) and the lane's key (cost << 6 | list index):
 // cost = SAD + |mv - mvp| (F/moestimation.cpp:460-468).  No wave-level reduction in here.
 template <int K>
-__device__ __forceinline__ void sad_keys(const WList &L, int cnt, int lane, const uint8_t *__restrict__ Ps, size_t ysz,
-                                         int W, int H, int sx, int sy, const SrcBlk &SB, int mvpx, int mvpy,
-                                         int &best, int &bestxy)
+__device__ __forceinline__ void sad_keys(const WList &L, int cnt, int lane, const IPlanes &ip, int W, int H, int sx, int sy,
+                                         const SrcBlk &SB, int mvpx, int mvpy, int &best, int &bestxy)
 {
     const bool on = lane < cnt && lane < K;
     const int cxv = on ? unp_x(L.xy) : 0, cyv = on ? unp_y(L.xy) : 0;
-    const int sad = sad_lane(Ps, ysz, W, H, sx, sy, cxv, cyv, SB);
+    const int sad = sad_lane(ip, W, H, sx, sy, cxv, cyv, SB);
     best = on ? ((sad + iabs(cxv - mvpx) + iabs(cyv - mvpy)) << 6) | lane : 0x7fffffff;
     bestxy = L.xy;
 }
@@ -915,7 +875,7 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
     const size_t ysz = d.ysz, csz = d.csz;
     uint8_t *Y = d.curY + (size_t)s * ysz;
     const uint8_t *RY = d.refY + (size_t)s * ysz;
-    const uint8_t *Ps = d.interp + (size_t)s * 16 * ysz;
+    const IPlanes ip = ip_stream(d, s);
     const uint16_t *Fs = d.feat + (size_t)s * 96 * ysz;
     const int xp = mbx << 4, yp = mby << 4;
     const int sx = gx * 8, sy = gy * 8;
@@ -937,7 +897,7 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
         uint32_t sv = *(const uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx);
 #pragma unroll
         for (int k = 0; k < 4; k++) srcv[k] = (sv >> (8 * k)) & 0xff;
-        mc_luma4(RY, Ps, ysz, W, H, xp, yp, lx, ly, smx, smy, pred);
+        mc_luma4(RY, ip, W, H, xp, yp, lx, ly, smx, smy, pred);
         int MAXDIFF = d.maxdiff_set;
         if (d.maxdiff_set == -1) {  // adaptive tolerance, F/moestimation.cpp:407-419
             int mean = wave_sum(srcv[0] + srcv[1] + srcv[2] + srcv[3]) / 256;
@@ -1009,7 +969,7 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
     }
     const int cnt1 = __popcll(__ballot(lane < 17 && L1.m < 100000000));
     int b1, b1xy;
-    sad_keys<17>(L1, cnt1, lane, Ps, ysz, W, H, sx, sy, P.sb, mvpx, mvpy, b1, b1xy);
+    sad_keys<17>(L1, cnt1, lane, ip, W, H, sx, sy, P.sb, mvpx, mvpy, b1, b1xy);
     wave_best(b1, b1xy, wkey, wxy);
     return false;
 }
@@ -1022,7 +982,7 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
 {
     const int W = d.W, H = d.H;
     const size_t ysz = d.ysz;
-    const uint8_t *Ps = d.interp + (size_t)s * 16 * ysz;
+    const IPlanes ip = ip_stream(d, s);
     const int sx = gx * 8, sy = gy * 8;
     k2 = k3 = 0x7fffffff;
     xy2 = xy3 = 0;
@@ -1037,7 +997,7 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
         L2.m = INF_M;
         L2.xy = 0;
         const SuPk sp = su_pack(P.su);
-        walk_buckets(d, s, P.su, sp, sx, sy, lane, [&](bool ok, int rank, int rel, int D) {
+        walk_buckets(d, s, P.su, sp, sx, sy, lane, (uint32_t *)sel_lds, [&](bool ok, int rank, int rel, int D) {
             (void)rank;
             int tx = rel >> 16, ty = (int)(short)(rel & 0xffff);
             wl_insert(L2, 33, lane, ok, (iabs(tx - genx) + iabs(ty - geny) + 4) * D, pack_xy(tx * 4, ty * 4));
@@ -1056,7 +1016,7 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
     }
     const int cnt2 = __popcll(__ballot(lane < 33 && L2.m < 100000000));
     int b2, b2xy;
-    sad_keys<33>(L2, cnt2, lane, Ps, ysz, W, H, sx, sy, P.sb, mvpx, mvpy, b2, b2xy);
+    sad_keys<33>(L2, cnt2, lane, ip, W, H, sx, sy, P.sb, mvpx, mvpy, b2, b2xy);
     wave_best(b2, b2xy, k2, xy2);
     int key = 0x7fffffff;
     if (lane < P.n3) key = ((P.c3s + iabs(P.c3x - mvpx) + iabs(P.c3y - mvpy)) << 6) | lane;
@@ -1297,7 +1257,7 @@ __global__ __launch_bounds__(64) void k_basic_stat(FerDev d)
     const int W = d.W, H = d.H;
     const uint8_t *Y = d.curY + (size_t)s * d.ysz;
     const uint8_t *RY = d.refY + (size_t)s * d.ysz;
-    const uint8_t *Ps = d.interp + (size_t)s * 16 * d.ysz;
+    const IPlanes ip = ip_stream(d, s);
     const int xp = (mb % d.mbw) << 4, yp = (mb / d.mbw) << 4;
     int src[4][4];
 #pragma unroll
@@ -1314,7 +1274,7 @@ __global__ __launch_bounds__(64) void k_basic_stat(FerDev d)
 #pragma unroll
         for (int y = 0; y < 4; y++) {
             int p[4];
-            mc_luma4(RY, Ps, d.ysz, W, H, xp, yp, 0, y, mvx, mvy, p);
+            mc_luma4(RY, ip, W, H, xp, yp, 0, y, mvx, mvy, p);
 #pragma unroll
             for (int k = 0; k < 4; k++) sad += iabs(src[y][k] - p[k]);
         }

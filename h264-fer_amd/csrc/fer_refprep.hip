@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k_interp(FerDev d)
     int s = blockIdx.z;
     if (d.hdr[s * 4 + 3] != 0) return;  // only P pictures search
     const uint8_t *R = d.refY + (size_t)s * d.ysz;
-    uint8_t *P = d.interp + (size_t)s * 16 * d.ysz;
+    uint8_t *P = d.interp + (size_t)s * 16 * d.iplane + d.ioff;
     int x0 = blockIdx.x * IT_W, y0 = blockIdx.y * IT_H;
     int tid = threadIdx.y * IT_W + threadIdx.x;
     for (int i = tid; i < (IT_H + 5) * (IT_W + 5); i += 256) {
@@ -60,9 +60,30 @@ __global__ __launch_bounds__(256) void k_interp(FerDev d)
     v[14] = FER_MID(j, sS);
     v[15] = FER_MID(sS, m);
 #undef T
-    size_t o = (size_t)y * d.W + x;
+    size_t o = (size_t)y * d.ipitch + x;
 #pragma unroll
-    for (int f = 0; f < 16; f++) P[(size_t)f * d.ysz + o] = (uint8_t)v[f];
+    for (int f = 0; f < 16; f++) P[(size_t)f * d.iplane + o] = (uint8_t)v[f];
+}
+
+// right and bottom margins of the 16 planes: pixel (x, y) beyond the picture = the plane's (min(x, W-1), min(y, H-1))
+__global__ __launch_bounds__(256) void k_interp_pad(FerDev d)
+{
+    const int s = blockIdx.z, f = blockIdx.y;
+    if (d.hdr[s * 4 + 3] != 0) return;
+    uint8_t *P = d.interp + ((size_t)s * 16 + f) * d.iplane + d.ioff;
+    const int W = d.W, H = d.H;
+    const int nr = FER_IP_R * H, nb = (W + FER_IP_R) * FER_IP_B;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nr + nb; i += gridDim.x * blockDim.x) {
+        int x, y;
+        if (i < nr) {
+            x = W + i % FER_IP_R;
+            y = i / FER_IP_R;
+        } else {
+            x = (i - nr) % (W + FER_IP_R);
+            y = H + (i - nr) / (W + FER_IP_R);
+        }
+        P[(size_t)y * d.ipitch + x] = P[(size_t)min(y, H - 1) * d.ipitch + min(x, W - 1)];
+    }
 }
 
 // ------------------------------------------------------------------ k_features
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(256) void k_features(FerDev d)
     if (d.hdr[s * 4 + 3] != 0) return;
     const int f = lane & 15, x = xg * 4 + (lane >> 4);
     const int W = d.W, H = d.H;
-    const uint8_t *P = d.interp + ((size_t)s * 16 + f) * d.ysz;
+    const uint8_t *P = d.interp + ((size_t)s * 16 + f) * d.iplane + d.ioff;
     const int y0 = strip * FS_ROWS, y1 = min(y0 + FS_ROWS, H);  // output rows [y0, y1)
     uint32_t *out = (uint32_t *)(d.feat + (size_t)s * 96 * d.ysz);
     const int sh = (int)((uintptr_t)(P + x) & 3);  // W is a multiple of 16: the same byte offset in every row
@@ -133,7 +154,7 @@ __global__ __launch_bounds__(256) void k_features(FerDev d)
         // waiting on one memory round trip per output row
         FeatRow rr[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) rr[j] = feat_row_load(P + (size_t)min(y0 + base + j, H - 1) * W, x);
+        for (int j = 0; j < 8; j++) rr[j] = feat_row_load(P + (size_t)min(y0 + base + j, H - 1) * d.ipitch, x);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int y = y0 + base + j;  // input row (clamped), completes the window of output row y - 7
@@ -521,6 +542,7 @@ void fer_launch_interp(const FerDev &d, hipStream_t st)
 {
     dim3 gi((d.W + IT_W - 1) / IT_W, (d.H + IT_H - 1) / IT_H, d.S);
     hipLaunchKernelGGL(k_interp, gi, dim3(IT_W, IT_H), 0, st, d);
+    hipLaunchKernelGGL(k_interp_pad, dim3(8, 16, d.S), dim3(256), 0, st, d);
 }
 
 void fer_launch_features(const FerDev &d, hipStream_t st)

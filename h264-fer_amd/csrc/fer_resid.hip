@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void k_p_resid(FerDev d)
         }
         int q = (ly >> 3) * 2 + (lx >> 3);
         int pf[4];
-        mc_luma4(RY, d.interp + (size_t)s * 16 * d.ysz, d.ysz, W, H, xp, yp, lx, ly, mvx[q], mvy[q], pf);
+        mc_luma4(RY, ip_stream(d, s), W, H, xp, yp, lx, ly, mvx[q], mvy[q], pf);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             pL[ly][lx + k] = (uint8_t)pf[k];
