@@ -213,7 +213,7 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     d.iplane = (((size_t)d.ipitch * (H + FER_IP_T + FER_IP_B)) + 255) & ~(size_t)255;
     d.ioff = FER_IP_T * d.ipitch + FER_IP_L;
     rc |= dalloc(c, &d.interp, decode_only ? (size_t)1 : (size_t)(d.iplane * 16 * S));
-    rc |= dalloc(c, &d.feat, decode_only ? (size_t)1 : (size_t)(d.ysz * 96 * S));
+    d.feat = nullptr;  // the 16-plane feature table exists only as a test read-back (FERHIP_BUF_FEAT)
     rc |= dalloc(c, &d.feat0, decode_only ? (size_t)1 : (size_t)(d.ysz * 6 * S));
     rc |= dalloc(c, &d.sort_pos, decode_only ? (size_t)1 : (size_t)(d.ysz * S));
     rc |= dalloc(c, &d.sort_rec, decode_only ? (size_t)1 : (size_t)(d.ysz * S * 3));
@@ -703,10 +703,6 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
                 ProfScope ps(c, FERHIP_PH_INTERP, 1);
                 fer_launch_interp(d, c->st);
             }
-            {
-                ProfScope ps(c, FERHIP_PH_FEATURES, 1);
-                fer_launch_features(d, c->st);
-            }
             // BasicInterEncoding never walks the buckets (F/moestimation.cpp:470): the sorted order is not built
             if (!d.basic) {
                 {
@@ -1025,7 +1021,17 @@ extern "C" size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t
                 return 0;
         return n;
     }
-    case FERHIP_BUF_FEAT: src = d.feat; n = d.ysz * 96 * d.S * 2; break;
+    case FERHIP_BUF_FEAT: {
+        // refFrameKar[0..4][frac] for every position: the searches derive what they need of it on chip, the full table
+        // is built here on request from the interpolated planes (parity tests of row a16)
+        n = d.ysz * 96 * d.S * 2;
+        if (n > cap) return 0;
+        if (!d.feat && dalloc(c, &d.feat, d.ysz * 96 * d.S)) return 0;
+        if (hipDeviceSynchronize() != hipSuccess) return 0;
+        fer_launch_features(d, c->st);
+        src = d.feat;
+        break;
+    }
     case FERHIP_BUF_SORTPOS: src = d.sort_pos; n = d.ysz * d.S * 4; break;
     case FERHIP_BUF_KOLIKO: {  // the reference's koliko[] = first level of the bucket index, relative to the stream's segment
         n = (size_t)16385 * d.S * 4;

@@ -270,13 +270,6 @@ __device__ __forceinline__ int feat_dist_rec(const uint16_t *__restrict__ rec, c
     const uint32_t *r = (const uint32_t *)rec;
     return feat_dist_w(r[0], r[1], r[2], p);
 }
-// ... at (frac, refy, refx) of the all-fracs array
-__device__ __forceinline__ int feat_dist(const uint16_t *__restrict__ Fs, size_t ysz, int W, int frac, int refy,
-                                         int refx, const SuPk &p)
-{
-    (void)ysz;
-    return feat_dist_rec(Fs + (((size_t)refy * W + refx) * 16 + frac) * 6, p);
-}
 // Record fetch without control flow: coordinates are clamped into the picture so that the load
 // can always be issued (the caller masks candidates outside the picture afterwards).  Loads
 // under a branch are waited for one by one; a wavefront that runs alone on its SIMD cannot
@@ -284,16 +277,122 @@ __device__ __forceinline__ int feat_dist(const uint16_t *__restrict__ Fs, size_t
 struct FeatRec {
     uint32_t a, b, c;
 };
-__device__ __forceinline__ FeatRec feat_load(const uint16_t *__restrict__ Fs, int W, int H, int frac, int refy, int refx)
+
+// ---- the five box features of one (position, quarter-pel plane) straight from the interpolated plane ----
+// refFrameKar[0..4][frac][refy][refx] of F/moestimation.cpp:105-138 for one candidate per lane: eight rows of eight
+// samples (the replicated margin of the planes stands in for the reference's 8-pixel padding).  ~80 instructions and
+// 8 loads per candidate: the general route (WindowSize other than 16 / 32); the searches of the specialised kernels
+// share the row sums of neighbouring candidates through LDS (local_metrics below).
+__device__ __forceinline__ FeatRec feat_rec_direct(const IPlanes &ip, int W, int H, int frac, int refy, int refx)
 {
-    int y = iclamp(refy, 0, H - 1), x = iclamp(refx, 0, W - 1);
-    const uint32_t *r = (const uint32_t *)(Fs + (((size_t)y * W + x) * 16 + frac) * 6);
+    const int y = iclamp(refy, 0, H - 1), x = iclamp(refx, 0, W - 1);
+    const uint8_t *p0 = ip.base + (size_t)frac * ip.plane + (size_t)y * ip.pitch + (x & ~3);
+    const uint32_t sh = (uint32_t)(x & 3);
+    uint32_t h84[8], hc[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t *w = (const uint32_t *)(p0 + (size_t)r * ip.pitch);
+        const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], sh), hi = __builtin_amdgcn_alignbyte(w[2], w[1], sh);
+        const uint32_t a4 = __builtin_amdgcn_sad_u8(lo, 0u, 0u);
+        h84[r] = __builtin_amdgcn_sad_u8(hi, 0u, a4) | (a4 << 16);
+        hc[r] = __builtin_amdgcn_sad_u8(hi & 0xffffu, 0u, __builtin_amdgcn_sad_u8(lo & 0xffffu, 0u, 0u));
+    }
+    const uint32_t top = h84[0] + h84[1] + h84[2] + h84[3], all = top + h84[4] + h84[5] + h84[6] + h84[7];
+    const uint32_t k3 = (h84[0] + h84[1] + h84[4] + h84[5]) & 0xffffu;
+    const uint32_t k4 = hc[0] + hc[1] + hc[2] + hc[3] + hc[4] + hc[5] + hc[6] + hc[7];
     FeatRec f;
-    f.a = r[0];
-    f.b = r[1];
-    f.c = r[2];
+    f.a = (all & 0xffffu) | (top << 16);  // k0 | k1 << 16
+    f.b = (all >> 16) | (k3 << 16);       // k2 | k3 << 16
+    f.c = k4;
     return f;
 }
+
+// ---- MEstimation(sx, sy, granica = R1, stepMV 1, stepFrac 1, genx, geny, px, py) without a feature table ----
+// The (2 R1 + 1)^2 integer positions around the centre on all 16 quarter-pel planes (F/moestimation.cpp:254-296):
+// candidate c = (ix * N1 + iy) * 16 + frac in the reference's loop order, metric (|ix - R1| + |iy - R1| + 4) * D
+// (both searches of interEncoding that use this shape weigh from their own centre), -1 outside the picture.
+// The box features are built on chip: for 8 planes at a time, lane = (plane, row) takes one 16-byte row of the
+// (2 R1 + 8)^2 patch of its plane and leaves the horizontal sums of every column offset in LDS; lane = (plane, column
+// offset) then runs down its column with prefix sums and emits the N1 metrics.  16-byte loads cover the patch for
+// R1 <= 2 (WindowSize 16 and 32).  htab: 8 * PW * N1 * 2 dwords, mtab: NB * 64 ints, both private to the wavefront.
+template <int R1>
+struct LocalGeo {
+    static constexpr int N1 = 2 * R1 + 1, PW = 2 * R1 + 8, NC = N1 * N1 * 16, NB = (NC + 63) / 64;
+    static constexpr int HTAB = 8 * PW * N1 * 2;
+};
+template <int R1>
+__device__ __forceinline__ void local_metrics(const IPlanes &ip, int W, int H, int px0, int py0, const SuPk &sp, int lane,
+                                              uint32_t *htab, int *mtab)
+{
+    using G = LocalGeo<R1>;
+    constexpr int N1 = G::N1, PW = G::PW;
+    static_assert(PW + 3 <= 16, "the patch row must fit one 16-byte load");
+    // px0, py0 = picture position of candidate (ix, iy) = (0, 0); nothing to do when no candidate is inside
+    if (px0 + N1 - 1 < 0 || px0 >= W || py0 + N1 - 1 < 0 || py0 >= H) {
+#pragma unroll
+        for (int u = 0; u < G::NB; u++) mtab[u * 64 + lane] = -1;
+        WAVE_LDS_SYNC();
+        return;
+    }
+    const uint32_t sh = (uint32_t)(px0 & 3);
+    const uint8_t *pbase = ip.base + (ptrdiff_t)py0 * ip.pitch + (px0 & ~3);
+    for (int half = 0; half < 2; half++) {
+        // ---- horizontal sums: row tasks (plane, row)
+#pragma unroll
+        for (int t0 = 0; t0 < 8 * PW; t0 += 64) {
+            const int t = t0 + lane;
+            const int tt = min(t, 8 * PW - 1);
+            const int fl = tt / PW, r = tt - fl * PW;
+            typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            const u32x4_a4 w = *(const u32x4_a4 *)(pbase + (size_t)(half * 8 + fl) * ip.plane + (size_t)r * ip.pitch);
+            const uint32_t b0 = __builtin_amdgcn_alignbyte(w.y, w.x, sh), b1 = __builtin_amdgcn_alignbyte(w.z, w.y, sh),
+                           b2 = __builtin_amdgcn_alignbyte(w.w, w.z, sh);
+            if (t < 8 * PW) {
+                uint32_t *o = htab + (size_t)tt * N1 * 2;
+#pragma unroll
+                for (int ix = 0; ix < N1; ix++) {
+                    const uint32_t lo = ix < 4 ? __builtin_amdgcn_alignbyte(b1, b0, (uint32_t)(ix & 3)) : b1;
+                    const uint32_t hi = ix < 4 ? __builtin_amdgcn_alignbyte(b2, b1, (uint32_t)(ix & 3)) : b2;
+                    const uint32_t a4 = __builtin_amdgcn_sad_u8(lo, 0u, 0u);
+                    o[ix * 2] = __builtin_amdgcn_sad_u8(hi, 0u, a4) | (a4 << 16);
+                    o[ix * 2 + 1] = __builtin_amdgcn_sad_u8(hi & 0xffffu, 0u, __builtin_amdgcn_sad_u8(lo & 0xffffu, 0u, 0u));
+                }
+            }
+        }
+        WAVE_LDS_SYNC();
+        // ---- column tasks (plane, column offset): prefix sums down the PW rows, N1 metrics
+        if (lane < 8 * N1) {
+            const int fl = lane / N1, ix = lane - fl * N1;
+            uint32_t P84[PW + 1], Pc[PW + 1];
+            P84[0] = 0;
+            Pc[0] = 0;
+#pragma unroll
+            for (int r = 0; r < PW; r++) {
+                const uint2 h = *(const uint2 *)(htab + ((size_t)(fl * PW + r) * N1 + ix) * 2);
+                P84[r + 1] = P84[r] + h.x;  // (sum of h8) | (sum of h4) << 16: neither field can carry
+                Pc[r + 1] = Pc[r] + h.y;
+            }
+            const int refx = px0 + ix, wx = iabs(ix - R1) + 4;
+            const bool xok = refx >= 0 && refx < W;
+#pragma unroll
+            for (int iy = 0; iy < N1; iy++) {
+                const uint32_t all = P84[iy + 8] - P84[iy];
+                const uint32_t k1 = (P84[iy + 4] - P84[iy]) & 0xffffu;
+                const uint32_t k3 = ((P84[iy + 2] - P84[iy]) + (P84[iy + 6] - P84[iy + 4])) & 0xffffu;
+                const uint32_t k4 = Pc[iy + 8] - Pc[iy];
+                const int D = feat_dist_w((all & 0xffffu) | (k1 << 16), (all >> 16) | (k3 << 16), k4, sp);
+                const int refy = py0 + iy;
+                const int m = (xok && refy >= 0 && refy < H) ? (wx + iabs(iy - R1)) * D : -1;
+                mtab[((ix * N1 + iy) << 4) + half * 8 + fl] = m;
+            }
+        }
+        WAVE_LDS_SYNC();
+    }
+#pragma unroll
+    for (int c = G::NC + lane; c < G::NB * 64; c += 64) mtab[c] = -1;  // the padding of the last batch
+    WAVE_LDS_SYNC();
+}
+
 // ... from the plane-0 copy [H][W][6]
 __device__ __forceinline__ FeatRec feat0_load(const uint16_t *__restrict__ F0, int W, int H, int refy, int refx)
 {
@@ -354,8 +453,11 @@ template <int WIN>  // WindowSize known at compile time (0 = read it from d): di
 __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
 {
     const int window = WIN ? WIN : d.window;
-    __shared__ int wide_m[ME_WIDE_LDS];
-    __shared__ __attribute__((aligned(16))) int sel_lds[256];
+    // LDS of the wavefront: region A = the row sums of the local search, then the wide search's metrics; region B =
+    // the local search's metrics, then the scratch of the selection
+    __shared__ __attribute__((aligned(16))) int wide_m[ME_WIDE_LDS];
+    __shared__ __attribute__((aligned(16))) int sel_lds[448];
+    static_assert(LocalGeo<2>::HTAB <= ME_WIDE_LDS && LocalGeo<2>::NB * 64 <= 448, "LDS regions of k_me_pre");
     const int lane = threadIdx.x;
     const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;
@@ -367,7 +469,6 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     const size_t ysz = d.ysz;
     const uint8_t *Y = d.curY + (size_t)s * ysz;
     const IPlanes ip = ip_stream(d, s);
-    const uint16_t *Fs = d.feat + (size_t)s * 96 * ysz;
     const int sx = ((mb % d.mbw) << 4) + (part & 1) * 8, sy = ((mb / d.mbw) << 4) + (part >> 1) * 8;
     const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
 
@@ -408,7 +509,9 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     const int r2 = window / 16, n2w = 2 * r2 + 1, nloc = n2w * n2w * 16;
     const uint16_t *F0 = d.feat0 + (size_t)s * 6 * ysz;
     const int wb = (n * n + 63) >> 6;  // batches of the wide search
-    if (n * n <= ME_WIDE_LDS && wb + ((nloc + 63) >> 6) <= ME_SEL_NB && !FER_DBGF(d, 3)) {
+    if ((WIN == 32 || WIN == 16) && !FER_DBGF(d, 3)) {
+        // the local search first (its row sums borrow the LDS of the wide search's metrics)
+        local_metrics<(WIN ? WIN : 32) / 16>(ip, W, H, sx - r2, sy - r2, sp, lane, (uint32_t *)wide_m, sel_lds);
         // pass A: lanes run along x (contiguous 12-byte records); metrics land in LDS at their
         // arrival index (tx outer, ty inner).  Records are fetched six batches at a time with
         // clamped coordinates (no control flow around the loads), then masked.
@@ -471,14 +574,8 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
         }
         __syncthreads();
         PP_MARK(1)
-        constexpr int LB = 7;  // batches of the local search that ME_SEL_NB leaves room for
-        FeatRec fl[LB];
-#pragma unroll
-        for (int q = 0; q < LB; q++) {
-            int c = q * 64 + lane;
-            int frac = c & 15, pos = c >> 4;
-            fl[q] = feat_load(Fs, W, H, frac, sy + pos % n2w - r2, sx + pos / n2w - r2);
-        }
+        constexpr int LB = LocalGeo<(WIN ? WIN : 32) / 16>::NB;  // batches of the local search
+        static_assert(LB <= 7, "ME_SEL_NB leaves room for 7 local batches");
         int v[ME_SEL_NB];
 #pragma unroll
         for (int u = 0; u < ME_SEL_NB; u++) {
@@ -487,15 +584,10 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
                 int c = u * 64 + lane;
                 if (c < n * n) v[u] = wide_m[c];
             } else if (u - wb < LB) {
-                int c = (u - wb) * 64 + lane;
-                int pos = c >> 4;
-                int tx = pos / n2w - r2, ty = pos % n2w - r2;
-                int rx = sx + tx, ry = sy + ty;
-                int m = (iabs(tx) + iabs(ty) + 4) * feat_dist_w(fl[u - wb < LB ? u - wb : 0].a, fl[u - wb < LB ? u - wb : 0].b,
-                                                                 fl[u - wb < LB ? u - wb : 0].c, sp);
-                if (c < nloc && rx >= 0 && rx < W && ry >= 0 && ry < H) v[u] = m;
+                v[u] = sel_lds[(u - wb < LB ? u - wb : 0) * 64 + lane];
             }
         }
+        WAVE_LDS_SYNC();  // the selection reuses sel_lds
         auto raw = [&](int u) { return u * 64 + lane; };  // arrival index
         auto fin = [&](int idx) {                          // ... to the candidate's vector
             if (idx < wb * 64) return pack_xy((idx / n - R) * 4, (idx % n - R) * 4);
@@ -523,7 +615,10 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
             int rx = sx + tx, ry = sy + ty;
             bool ok = c < nloc && rx >= 0 && rx < W && ry >= 0 && ry < H;
             int m = 0;
-            if (ok) m = (iabs(tx) + iabs(ty) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, sp);
+            if (ok) {
+                const FeatRec f = feat_rec_direct(ip, W, H, frac, ry, rx);
+                m = (iabs(tx) + iabs(ty) + 4) * feat_dist_w(f.a, f.b, f.c, sp);
+            }
             wl_insert(L, 33, lane, ok, m, pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2)));
         }
     }
@@ -559,25 +654,23 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
 // sink(ok, rank, rel, D) is called for every batch by all lanes: ok = the lane holds a candidate, rank = its
 // arrival index, rel = (tx - sx) << 16 | (ty - sy) & 0xffff, D = its feature distance.  Returns the count.
 // tbl = 128 dwords of LDS private to the calling wavefront.
-template <class SINK>
-__device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&su)[5], const SuPk &sp, int sx, int sy, int lane,
-                                            uint32_t *tbl, SINK sink)
+template <bool QUIRK, class SINK>
+__device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int (&su)[5], const SuPk &sp, int sx, int sy, int lane,
+                                              uint32_t *tbl, SINK sink)
 {
     int tren = 0;
-    if (d.basic || FER_DBGF(d, 8)) return 0;
     const int kt = d.kt;
     const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * kt;
     const uint32_t *srec = d.sort_rec;  // indexed by the device-wide positions kol2 holds
-    // A stream whose reference picture has n0 > 0 positions of sum 0 carries the reference's mis-filed bucket layout
-    // (k_sort_quirk): whole buckets are scanned by its rules -- bucket 0 = [0, 2 n0), bucket 1 from 2 n0, the others
-    // n0 places early, the last one up to the end of the array --, and a record may sit in a bucket it does not
+    // QUIRK: a stream whose reference picture has n0 > 0 positions of sum 0 carries the reference's mis-filed bucket
+    // layout (k_sort_quirk): whole buckets are scanned by its rules -- bucket 0 = [0, 2 n0), bucket 1 from 2 n0, the
+    // others n0 places early, the last one up to the end of the array --, and a record may sit in a bucket it does not
     // belong to (or be left over from the previous picture), so its distance is taken from the features at its
     // position, as the reference does, not from the record.
-    const int n0 = d.zero_cnt[s];
-    const bool quirk = n0 > 0;
+    const int n0 = QUIRK ? d.zero_cnt[s] : 0;
     const uint32_t npos = (uint32_t)(d.W * d.H), g0 = (uint32_t)s * npos;
     const uint16_t *F0 = d.feat0 + (size_t)s * 6 * d.ysz;
-    const int t_lo = quirk ? 0 : (max(sx - 279, 0) >> d.ktw_shift), t_hi = quirk ? kt - 1 : (min(sx + 279, d.W - 1) >> d.ktw_shift);
+    const int t_lo = QUIRK ? 0 : (max(sx - 279, 0) >> d.ktw_shift), t_hi = QUIRK ? kt - 1 : (min(sx + 279, d.W - 1) >> d.ktw_shift);
     auto qstart = [&](int a) -> uint32_t {  // first place of bucket a in the mis-filed layout
         if (a <= 0) return g0;
         if (a == 1) return g0 + min(2u * (uint32_t)n0, npos);
@@ -585,25 +678,29 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
         return kol2[(size_t)a * kt] - (uint32_t)n0;
     };
     const uint32_t sxy = ((uint32_t)sx << 16) | (uint32_t)sy;  // the records' (tx << 16) | ty pairing
-    // descriptor of a batch: start record; count (bits 0-6) | last-of-step (bit 7) | bucket << 8
+    // Descriptor of a batch, one per lane: first record; count (bits 0-6) | last batch of its step (bit 7) | step j
+    // (bits 8-15) | bucket (bits 16-30).  Lanes beyond the last batch hold an empty batch at a readable address, so
+    // the loop can fetch two batches ahead without tests.
     auto fetch = [&](unsigned b_start, int b_cnt, uint32_t &r0, uint32_t &r1, uint32_t &r2) {
         const uint32_t *e = srec + (size_t)(b_start + (unsigned)min(lane, max(b_cnt - 1, 0))) * 3;
         r0 = e[0];
         r1 = e[1];
         r2 = e[2];
     };
-    auto filter = [&](int b_cnt, int a, uint32_t r0, uint32_t r1, uint32_t r2) {
+    auto filter = [&](uint32_t info, uint32_t r0, uint32_t r1, uint32_t r2) {
         // |tx - sx| + |ty - sy| < 280 and both half sums within 100, on u16 pairs
+        const int b_cnt = (int)(info & 127u);
         uint32_t dist = __builtin_amdgcn_sad_u16(r0, sxy, 0);
         uint32_t e12 = pk_abs16(pk_sub16(r1, sp.s12));
         bool ok = lane < b_cnt && dist < 280u && (pk_sub16(e12, 0x00640064u) & 0x80008000u) == 0x80008000u;
         unsigned long long mk = __ballot(ok);
         int rank = tren + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
         uint32_t D;
-        if (!quirk) {
-            // feature distance from the sorted payload (kar0 == a): |s0-a| + sum |si-qi| + sum |(s0-si) - (a-qi)|
-            uint32_t aa = (uint32_t)a | ((uint32_t)a << 16);
-            D = __builtin_amdgcn_sad_u16(r1, sp.s12, (uint32_t)iabs(su[0] - a));
+        if (!QUIRK) {
+            // feature distance from the sorted payload (kar0 == a): |s0-a| + sum |si-qi| + sum |(s0-si) - (a-qi)|;
+            // |s0 - a| is the step j
+            const uint32_t aa = (info >> 16) * 0x10001u;
+            D = __builtin_amdgcn_sad_u16(r1, sp.s12, (info >> 8) & 255u);
             D = __builtin_amdgcn_sad_u16(r2, sp.s34, D);
             D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r1), sp.e12, D);
             D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r2), sp.e34, D);
@@ -614,33 +711,33 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
         sink(ok, rank, (int)pk_sub16(r0, sxy), (int)D);
         tren += __popcll(mk);
     };
-    // runs the nb <= 64 batches whose descriptors sit one per lane; true = the walk is over
+    // runs the nb <= 62 batches whose descriptors sit one per lane (lanes >= nb: empty batches); true = the walk is over
     auto run_table = [&](uint32_t dstart, uint32_t dinfo, int nb) -> bool {
-        auto desc = [&](int b, unsigned &bs, int &bc, int &ba, int &bl) {
+        auto desc = [&](int b, unsigned &bs, uint32_t &bi) {
             const int bb = min(b, 63);
-            const uint32_t st_ = (uint32_t)__builtin_amdgcn_readlane((int)dstart, bb), in_ = (uint32_t)__builtin_amdgcn_readlane((int)dinfo, bb);
-            bs = b < nb ? st_ : g0;
-            bc = b < nb ? (int)(in_ & 127u) : 0;
-            ba = (int)(in_ >> 8);
-            bl = b < nb ? (int)((in_ >> 7) & 1u) : 0;
+            bs = (unsigned)__builtin_amdgcn_readlane((int)dstart, bb);
+            bi = (uint32_t)__builtin_amdgcn_readlane((int)dinfo, bb);
         };
         unsigned sA, sB;
-        int cA, cB, aA, aB, lA, lB;
+        uint32_t iA, iB;
         uint32_t A0, A1, A2, B0, B1, B2;
-        desc(0, sA, cA, aA, lA);
-        fetch(sA, cA, A0, A1, A2);
-        desc(1, sB, cB, aB, lB);
-        fetch(sB, cB, B0, B1, B2);
+        desc(0, sA, iA);
+        fetch(sA, (int)(iA & 127u), A0, A1, A2);
+        desc(1, sB, iB);
+        fetch(sB, (int)(iB & 127u), B0, B1, B2);
         for (int b = 0; b < nb; b += 2) {  // two batches in flight, no register copies between them
-            filter(cA, aA, A0, A1, A2);
-            if (lA && tren > 128) return true;
-            desc(b + 2, sA, cA, aA, lA);
-            fetch(sA, cA, A0, A1, A2);
-            if (b + 1 >= nb) break;
-            filter(cB, aB, B0, B1, B2);
-            if (lB && tren > 128) return true;
-            desc(b + 3, sB, cB, aB, lB);
-            fetch(sB, cB, B0, B1, B2);
+            filter(iA, A0, A1, A2);
+            if (iA & 128u) {
+                if (tren > 128) return true;
+            }
+            desc(b + 2, sA, iA);
+            fetch(sA, (int)(iA & 127u), A0, A1, A2);
+            filter(iB, B0, B1, B2);  // an empty batch when b + 1 == nb
+            if (iB & 128u) {
+                if (tren > 128) return true;
+            }
+            desc(b + 3, sB, iB);
+            fetch(sB, (int)(iB & 127u), B0, B1, B2);
         }
         return false;
     };
@@ -652,7 +749,7 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
             const int which = lane >> 4, jj = j0 + (lane & 15);
             const int a = (which & 2) ? su[0] + jj : su[0] - jj;
             const bool va = a >= 0 && a < 16384 && jj <= 180;
-            if (!quirk) {
+            if (!QUIRK) {
                 if (va) kb = kol2[(size_t)a * kt + ((which & 1) ? t_hi + 1 : t_lo)];
             } else {
                 if (va) kb = qstart(a + (which & 1));
@@ -664,6 +761,7 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
         const uint32_t cnt = (lane < 32 && en > st) ? en - st : 0u;
         const int nb = (int)((cnt + 63u) >> 6);
         const int a_k = side ? su[0] + j0 + step : su[0] - (j0 + step);
+        const uint32_t ja = ((uint32_t)(j0 + step) << 8) | ((uint32_t)(a_k & 0x7fff) << 16);
         int pre = nb;  // inclusive prefix over the lanes
 #pragma unroll
         for (int o = 1; o < 32; o <<= 1) {
@@ -672,16 +770,19 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
         }
         const int TB = __builtin_amdgcn_readlane(pre, 31);
         if (TB == 0) continue;
-        if (TB <= 64) {
+        if (TB <= 62) {
             // the step's last batch: the high side's last one, or the low side's when the high side is empty
             const int nb_hi = __shfl(nb, lane | 1);
             const bool closes = side == 1 || nb_hi == 0;
+            tbl[lane] = g0;  // empty batches behind the last one
+            tbl[64 + lane] = 0u;
+            WAVE_LDS_SYNC();
             for (int i = 0; __any(i < nb); i++) {
                 if (i < nb) {
                     const int b = pre - nb + i;
                     const uint32_t c = min(cnt - 64u * (uint32_t)i, 64u);
                     tbl[b] = st + 64u * (uint32_t)i;
-                    tbl[64 + b] = c | ((closes && i == nb - 1) ? 128u : 0u) | ((uint32_t)a_k << 8);
+                    tbl[64 + b] = c | ((closes && i == nb - 1) ? 128u : 0u) | ja;
                 }
             }
             WAVE_LDS_SYNC();
@@ -689,22 +790,31 @@ __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&
             WAVE_LDS_SYNC();
             if (run_table(dstart, dinfo, TB)) return tren;
         } else {
-            // a crowded group: slice by slice, 64 batches of a slice at a time
+            // a crowded group: slice by slice, 62 batches of a slice at a time
             for (int k = 0; k < 32; k++) {
                 const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)st, k), kc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, k);
-                const int ka = __builtin_amdgcn_readlane(a_k, k);
+                const uint32_t kja = (uint32_t)__builtin_amdgcn_readlane((int)ja, k);
                 const int knb = (int)((kc + 63u) >> 6);
-                for (int b0 = 0; b0 < knb; b0 += 64) {
-                    const int m = min(64, knb - b0);
+                for (int b0 = 0; b0 < knb; b0 += 62) {
+                    const int m = min(62, knb - b0);
                     const uint32_t off = 64u * (uint32_t)(b0 + lane);
-                    const uint32_t c = lane < m ? min(kc - off, 64u) : 0u;
-                    if (run_table(ks + off, c | ((uint32_t)ka << 8), m)) return tren;  // stop tests fall between steps only
+                    const bool on = lane < m;
+                    if (run_table(on ? ks + off : g0, on ? (min(kc - off, 64u) | kja) : 0u, m)) return tren;  // stop tests fall between steps only
                 }
                 if ((k & 1) && tren > 128) return tren;
             }
         }
     }
     return tren;
+}
+
+template <class SINK>
+__device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&su)[5], const SuPk &sp, int sx, int sy, int lane,
+                                            uint32_t *tbl, SINK sink)
+{
+    if (d.basic || FER_DBGF(d, 8)) return 0;
+    if (d.zero_cnt[s] > 0) return walk_buckets_q<true>(d, s, su, sp, sx, sy, lane, tbl, sink);
+    return walk_buckets_q<false>(d, s, su, sp, sx, sy, lane, tbl, sink);
 }
 
 // ------------------------------------------------------------------ k_me_walk
@@ -866,7 +976,7 @@ __device__ __forceinline__ void wave_best(int best, int bestxy, int &wkey, int &
 // role 0: P_Skip test (partition 0) and stage 1.  Returns skip; otherwise the best stage-1 (key, vector).
 template <int WIN>
 __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
-                                               int *sel_lds, int &skipw, int &wkey, int &wxy)
+                                               int *sel_lds, uint32_t *loc_lds, int &skipw, int &wkey, int &wxy)
 {
     const int window = WIN ? WIN : d.window;
     const int mbx = gx >> 1, mby = gy >> 1, part = (gy & 1) * 2 + (gx & 1);
@@ -876,7 +986,6 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
     uint8_t *Y = d.curY + (size_t)s * ysz;
     const uint8_t *RY = d.refY + (size_t)s * ysz;
     const IPlanes ip = ip_stream(d, s);
-    const uint16_t *Fs = d.feat + (size_t)s * 96 * ysz;
     const int xp = mbx << 4, yp = mby << 4;
     const int sx = gx * 8, sy = gy * 8;
     wkey = 0x7fffffff;
@@ -935,26 +1044,14 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
         int frac = cc & 15, pos = cc >> 4;
         return pack_xy((genx - r1 + pos / n1) * 4 + (frac & 3), (geny - r1 + pos % n1) * 4 + (frac >> 2));
     };
-    if (tot1 <= 64 * ST1_UNROLL) {
-        FeatRec fr[ST1_UNROLL];
+    if (WIN == 32 || WIN == 16) {
+        constexpr int RR = (WIN ? WIN : 32) / 16;
+        constexpr int NB1 = LocalGeo<RR>::NB;
+        local_metrics<RR>(ip, W, H, sx + genx - r1, sy + geny - r1, sp, lane, loc_lds, (int *)loc_lds + LocalGeo<RR>::HTAB);
+        int m[NB1];
 #pragma unroll
-        for (int u = 0; u < ST1_UNROLL; u++) {
-            int cc = u * 64 + lane;
-            int frac = cc & 15, pos = cc >> 4;
-            fr[u] = feat_load(Fs, W, H, frac, sy + geny - r1 + pos % n1, sx + genx - r1 + pos / n1);
-        }
-        int m[ST1_UNROLL];
-#pragma unroll
-        for (int u = 0; u < ST1_UNROLL; u++) {
-            int cc = u * 64 + lane;
-            int pos = cc >> 4;
-            int tx = genx - r1 + pos / n1, ty = geny - r1 + pos % n1;
-            int rx = sx + tx, ry = sy + ty;
-            bool ok = cc < tot1 && rx >= 0 && rx < W && ry >= 0 && ry < H;
-            int mm = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist_w(fr[u].a, fr[u].b, fr[u].c, sp);
-            m[u] = ok ? mm : -1;
-        }
-        select_topk<ST1_UNROLL>(m, 17, lane, sel_lds, L1, raw1, fin1);
+        for (int u = 0; u < NB1; u++) m[u] = FER_DBGF(d, 16) ? -1 : ((const int *)loc_lds)[LocalGeo<RR>::HTAB + u * 64 + lane];
+        select_topk<NB1>(m, 17, lane, sel_lds, L1, raw1, fin1);
     } else {
         for (int base = 0; base < tot1; base += 64) {
             int cc = base + lane;
@@ -963,7 +1060,10 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
             int rx = sx + tx, ry = sy + ty;
             bool ok = cc < tot1 && rx >= 0 && rx < W && ry >= 0 && ry < H;
             int m = 0;
-            if (ok) m = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist(Fs, ysz, W, frac, ry, rx, sp);
+            if (ok) {
+                const FeatRec f = feat_rec_direct(ip, W, H, frac, ry, rx);
+                m = (iabs(tx - genx) + iabs(ty - geny) + 4) * feat_dist_w(f.a, f.b, f.c, sp);
+            }
             wl_insert(L1, 17, lane, ok, m, pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2)));
         }
     }
@@ -1062,6 +1162,7 @@ template <int WIN>
 __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
 {
     __shared__ __attribute__((aligned(16))) int sel_all[2][256];
+    __shared__ __attribute__((aligned(16))) uint32_t loc_lds[LocalGeo<2>::HTAB + LocalGeo<2>::NB * 64];  // local search of wavefront 0
     __shared__ int xch[8];
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1169,7 +1270,7 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
         if (part == 0 || !skip) {  // the same decision in both wavefronts: the barriers below are uniform
             if (role == 0) {
                 int skipw, k1, xy1;
-                bool sk = resolve_stage1<WIN>(d, s, gx, gy, ln, cur, N, sel_lds, skipw, k1, xy1);
+                bool sk = resolve_stage1<WIN>(d, s, gx, gy, ln, cur, N, sel_lds, loc_lds, skipw, k1, xy1);
                 PR_MARK(1)
                 __syncthreads();  // stage 2/3 results are in xch[0..3]
                 PR_MARK(2)

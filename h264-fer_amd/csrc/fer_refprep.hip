@@ -591,7 +591,6 @@ void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStr
 {
     (void)types;
     fer_launch_interp(d, st);
-    fer_launch_features(d, st);
     fer_launch_sort(d, t, st);
 }
 
