@@ -50,10 +50,9 @@ CONFIGS = {
 # phase -> (kernel, algorithmic bytes per macroblock, limiter, runs on "P" / "I" / "all" pictures)
 KERNELS = {
     "interp": ("k_interp", 256 + 16 * 256, "hbm", "P"),
-    "features": ("k_features", 16 * 256 + 256 * (192 + 12), "hbm", "P"),
-    "sort_keys": ("k_sort_keys", 256 * (2 + 8), "hbm", "P"),
-    "sort": ("k_rs_hist+k_rs_scan+k_rs_scatter (two radix passes)", 2 * 256 * (4 + 8 + 8), "hbm", "P"),
-    "sort_finish": ("k_sort_finish", 256 * (8 + 12 + 16), "hbm", "P"),
+    "sort_keys": ("k_feat0", 256 + 256 * (12 + 16 + 2), "hbm", "P"),
+    "sort": ("k_rs_hist+k_rs_scan+k_rs_scatter (two radix passes)", 256 * (2 + 1 + 2 + 16 + 16 + 1 + 1 + 16 + 12 + 4 + 2), "hbm", "P"),
+    "sort_finish": ("k_sort_index+k_sort_quirk", 256 * 6 + 1956, "hbm", "P"),
     "me_pre": ("k_me_pre", ME_BYTES_PER_MB, "valu", "P"),
     "me_walk": ("k_me_walk", ME_BYTES_PER_MB, "valu", "P"),
     "me_resolve": ("k_me_resolve", ME_BYTES_PER_MB, "valu", "P"),
@@ -213,8 +212,9 @@ def main():
     nmb = encs[0].nmb
     fsz = W * H * 3 // 2
     for e in encs:
-        if args.resolve_wgs:
-            e.tune(1, args.resolve_wgs)
+        # the persistent motion-chain launch of a context takes its share of the GPU's workgroup slots: with two
+        # contexts each leaves room for the other's streaming kernels
+        e.tune(1, args.resolve_wgs or max(768, 3072 // NC))
         if args.resolve_group:
             e.tune(2, args.resolve_group)
 

@@ -59,6 +59,10 @@ struct FerDev {
     // t == kt is the next bucket's first.  koliko[a] of the reference = kol2[(s*16384 + a)*kt] - s*W*H.
     uint32_t *kol2;      // [S*16384*kt + 1]
     int kt, ktw_shift;
+    // per bucket (8x8 sum) the ranges of the other four sums over its positions: [S][16384][8] = max of k1..k4, then max of
+    // 65535 - k1..k4 (so that one atomicMax and a zero fill serve both ends); 0 / 0 = empty bucket.  Lower bounds of the
+    // feature distance for crowded partitions (k_me_walk).
+    uint32_t *brange;
     int *zero_cnt;       // [S] positions of the reference picture whose 8x8 sum is 0 (see "bucket 0" in k_sort_finish)
     // per-MB side information (a20)
     int *mb_type;        // [S][nmb]

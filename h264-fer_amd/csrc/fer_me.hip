@@ -652,13 +652,16 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
 // its step" (where the stop test falls).  The batch loop reads descriptors with v_readlane, two batches in flight.
 // Groups of steps with more than 64 batches (flat content: thousands of positions per sum) go slice by slice.
 // sink(ok, rank, rel, D) is called for every batch by all lanes: ok = the lane holds a candidate, rank = its
-// arrival index, rel = (tx - sx) << 16 | (ty - sy) & 0xffff, D = its feature distance.  Returns the count.
+// arrival index, rel = (tx - sx) << 16 | (ty - sy) & 0xffff, D = its feature distance, info = the batch descriptor
+// (step and side, see below); it returns true to end the
+// walk at once (wave-uniform).  Returns the count; jend = the step j the walk ended in.
 // tbl = 128 dwords of LDS private to the calling wavefront.
 template <bool QUIRK, class SINK>
 __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int (&su)[5], const SuPk &sp, int sx, int sy, int lane,
-                                              uint32_t *tbl, SINK sink)
+                                              uint32_t *tbl, int &jend, SINK sink)
 {
     int tren = 0;
+    jend = 180;  // last step whose buckets belong to the candidate set
     const int kt = d.kt;
     const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * kt;
     const uint32_t *srec = d.sort_rec;  // indexed by the device-wide positions kol2 holds
@@ -679,7 +682,7 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
     };
     const uint32_t sxy = ((uint32_t)sx << 16) | (uint32_t)sy;  // the records' (tx << 16) | ty pairing
     // Descriptor of a batch, one per lane: first record; count (bits 0-6) | last batch of its step (bit 7) | step j
-    // (bits 8-15) | bucket (bits 16-30).  Lanes beyond the last batch hold an empty batch at a readable address, so
+    // (bits 8-15) | bucket (bits 16-30) | side (bit 31: 0 = su[0] - j, 1 = su[0] + j).  Lanes beyond the last batch hold an empty batch at a readable address, so
     // the loop can fetch two batches ahead without tests.
     auto fetch = [&](unsigned b_start, int b_cnt, uint32_t &r0, uint32_t &r1, uint32_t &r2) {
         const uint32_t *e = srec + (size_t)(b_start + (unsigned)min(lane, max(b_cnt - 1, 0))) * 3;
@@ -687,7 +690,7 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
         r1 = e[1];
         r2 = e[2];
     };
-    auto filter = [&](uint32_t info, uint32_t r0, uint32_t r1, uint32_t r2) {
+    auto filter = [&](uint32_t info, uint32_t r0, uint32_t r1, uint32_t r2) -> bool {
         // |tx - sx| + |ty - sy| < 280 and both half sums within 100, on u16 pairs
         const int b_cnt = (int)(info & 127u);
         uint32_t dist = __builtin_amdgcn_sad_u16(r0, sxy, 0);
@@ -699,7 +702,7 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
         if (!QUIRK) {
             // feature distance from the sorted payload (kar0 == a): |s0-a| + sum |si-qi| + sum |(s0-si) - (a-qi)|;
             // |s0 - a| is the step j
-            const uint32_t aa = (info >> 16) * 0x10001u;
+            const uint32_t aa = ((info >> 16) & 0x7fffu) * 0x10001u;
             D = __builtin_amdgcn_sad_u16(r1, sp.s12, (info >> 8) & 255u);
             D = __builtin_amdgcn_sad_u16(r2, sp.s34, D);
             D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r1), sp.e12, D);
@@ -708,8 +711,9 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
             int px = min((int)(r0 >> 16), d.W - 1), py = min((int)(r0 & 0xffff), d.H - 1);
             D = (uint32_t)feat_dist_rec(F0 + ((size_t)py * d.W + px) * 6, sp);
         }
-        sink(ok, rank, (int)pk_sub16(r0, sxy), (int)D);
+        const bool halt = sink(ok, rank, (int)pk_sub16(r0, sxy), (int)D, info);
         tren += __popcll(mk);
+        return halt;
     };
     // runs the nb <= 62 batches whose descriptors sit one per lane (lanes >= nb: empty batches); true = the walk is over
     auto run_table = [&](uint32_t dstart, uint32_t dinfo, int nb) -> bool {
@@ -726,15 +730,27 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
         desc(1, sB, iB);
         fetch(sB, (int)(iB & 127u), B0, B1, B2);
         for (int b = 0; b < nb; b += 2) {  // two batches in flight, no register copies between them
-            filter(iA, A0, A1, A2);
+            if (filter(iA, A0, A1, A2)) {  // the sink has what it wanted
+                jend = (int)((iA >> 8) & 255u);
+                return true;
+            }
             if (iA & 128u) {
-                if (tren > 128) return true;
+                if (tren > 128) {
+                    jend = (int)((iA >> 8) & 255u);
+                    return true;
+                }
             }
             desc(b + 2, sA, iA);
             fetch(sA, (int)(iA & 127u), A0, A1, A2);
-            filter(iB, B0, B1, B2);  // an empty batch when b + 1 == nb
+            if (filter(iB, B0, B1, B2)) {  // (an empty batch when b + 1 == nb)
+                jend = (int)((iB >> 8) & 255u);
+                return true;
+            }
             if (iB & 128u) {
-                if (tren > 128) return true;
+                if (tren > 128) {
+                    jend = (int)((iB >> 8) & 255u);
+                    return true;
+                }
             }
             desc(b + 3, sB, iB);
             fetch(sB, (int)(iB & 127u), B0, B1, B2);
@@ -761,7 +777,7 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
         const uint32_t cnt = (lane < 32 && en > st) ? en - st : 0u;
         const int nb = (int)((cnt + 63u) >> 6);
         const int a_k = side ? su[0] + j0 + step : su[0] - (j0 + step);
-        const uint32_t ja = ((uint32_t)(j0 + step) << 8) | ((uint32_t)(a_k & 0x7fff) << 16);
+        const uint32_t ja = ((uint32_t)(j0 + step) << 8) | ((uint32_t)(a_k & 0x7fff) << 16) | ((uint32_t)side << 31);
         int pre = nb;  // inclusive prefix over the lanes
 #pragma unroll
         for (int o = 1; o < 32; o <<= 1) {
@@ -801,7 +817,10 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
                     const bool on = lane < m;
                     if (run_table(on ? ks + off : g0, on ? (min(kc - off, 64u) | kja) : 0u, m)) return tren;  // stop tests fall between steps only
                 }
-                if ((k & 1) && tren > 128) return tren;
+                if ((k & 1) && tren > 128) {
+                    jend = j0 + (k >> 1);
+                    return tren;
+                }
             }
         }
     }
@@ -810,11 +829,12 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
 
 template <class SINK>
 __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&su)[5], const SuPk &sp, int sx, int sy, int lane,
-                                            uint32_t *tbl, SINK sink)
+                                            uint32_t *tbl, int &jend, SINK sink)
 {
+    jend = 0;
     if (d.basic || FER_DBGF(d, 8)) return 0;
-    if (d.zero_cnt[s] > 0) return walk_buckets_q<true>(d, s, su, sp, sx, sy, lane, tbl, sink);
-    return walk_buckets_q<false>(d, s, su, sp, sx, sy, lane, tbl, sink);
+    if (d.zero_cnt[s] > 0) return walk_buckets_q<true>(d, s, su, sp, sx, sy, lane, tbl, jend, sink);
+    return walk_buckets_q<false>(d, s, su, sp, sx, sy, lane, tbl, jend, sink);
 }
 
 // ------------------------------------------------------------------ k_me_walk
@@ -847,9 +867,85 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
     const SuPk sp = su_pack(su);
     int2 *out = (int2 *)(d.st2 + pidx * FER_ST2_CAP * 2);
     __shared__ uint32_t tbl[128];
-    const int tren = walk_buckets(d, s, su, sp, sx, sy, lane, tbl, [&](bool ok, int rank, int rel, int D) {
+    int jend;
+    // more than FER_ST2_CAP candidates make the partition "crowded" (below): the count itself is not needed then, and
+    // the step the stop test would fire in is the current one (the count is already past 128)
+    const int tren = walk_buckets(d, s, su, sp, sx, sy, lane, tbl, jend, [&](bool ok, int rank, int rel, int D, uint32_t) {
         if (ok && rank < FER_ST2_CAP) out[rank] = make_int2(rel, D);
+        return __any(ok && rank >= FER_ST2_CAP) && d.zero_cnt[s] == 0;
     });
+    if (tren > FER_ST2_CAP && d.zero_cnt[s] == 0) {
+        // A crowded partition (flat areas: thousands of positions share a feature vector).  k_me_resolve will not go
+        // through the candidates again; it looks for the winners around the predictor (resolve_crowded), for which it
+        // needs the last step J of the walk, the smallest positive distance among the candidates, and the candidates
+        // of distance 0 -- their metric is 0 whatever the predictor, so the first 33 of them in arrival order lead the
+        // list.  A second walk with another sink collects that; the list of the first 384 is not used then.
+        // A lower bound of the feature distance over the whole candidate set comes from the ranges the other four sums
+        // take in each bucket (FerDev.brange): |s - k| >= the distance of s from the range of k.  It also tells whether
+        // a candidate of distance 0 can exist at all (only in bucket su[0], and only if every range contains its sum).
+        int zc = 0, dmin = 0x7fffffff;
+        bool zeros_possible = false;
+        {
+            const uint32_t *brs = d.brange + (size_t)s * 16384 * 8;
+            for (int b0 = -jend; b0 <= jend; b0 += 64) {
+                const int dj = b0 + lane;
+                const int a = su[0] + dj;
+                int lb = 0x7fffffff;
+                if (dj <= jend && a >= 0 && a < 16384) {
+                    const uint4 hi = *(const uint4 *)(brs + (size_t)a * 8), lo = *(const uint4 *)(brs + (size_t)a * 8 + 4);
+                    const uint32_t h[4] = {hi.x, hi.y, hi.z, hi.w}, l[4] = {lo.x, lo.y, lo.z, lo.w};
+                    if (l[0] != 0) {  // the bucket holds something
+                        lb = iabs(dj);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int kmin = 65535 - (int)l[k], kmax = (int)h[k];
+                            const int s1 = su[k + 1], s2 = su[k + 1] + dj;  // |s_k - k_k| and |(s_0 - s_k) - (a - k_k)| = |k_k - (s_k + dj)|
+                            lb += max(max(kmin - s1, s1 - kmax), 0) + max(max(kmin - s2, s2 - kmax), 0);
+                        }
+                        if (dj == 0 && lb == 0) zeros_possible = true;
+                    }
+                }
+                dmin = min(dmin, lb);
+            }
+            dmin = max(wave_min(dmin), 1);  // what the ring scan weighs has a distance of at least 1
+            zeros_possible = __any(zeros_possible);
+        }
+        if (zeros_possible) {
+            // Look for them.  When the walk ended in step 0 its second half -- bucket su[0] again, from the other side --
+            // holds the same positions as the first: it is not read, its candidates of distance 0 are the first
+            // half's, repeated.  (A scan that runs to the end also gives the exact smallest positive distance.)
+            int j2, dpos = 0x7fffffff;
+            bool complete = true;
+            walk_buckets(d, s, su, sp, sx, sy, lane, tbl, j2, [&](bool ok, int rank, int rel, int D, uint32_t info) {
+                (void)rank;
+                if (jend == 0 && (info >> 31)) return true;
+                const bool z = ok && D == 0;
+                const unsigned long long mz = __ballot(z);
+                const int zr = zc + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mz, 0u));
+                if (z && zr < 33) out[zr] = make_int2(rel, 0);
+                zc += __popcll(mz);
+                if (ok && D > 0) dpos = min(dpos, D);
+                if (zc >= 33) complete = false;
+                return zc >= 33;  // 33 candidates of distance 0 are the whole list: nothing else is needed
+            });
+            if (complete) {
+                dpos = wave_min(dpos);
+                if (dpos != 0x7fffffff) dmin = dpos;
+            }
+            if (jend == 0 && zc < 33) {  // the repeats of the second visit
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the list is read back
+                // (agent-scope load: served by L2, where the stores above have landed)
+                const unsigned long long ev = __hip_atomic_load((const unsigned long long *)&out[min(lane, 32)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int2 e = make_int2((int)(unsigned)ev, (int)(unsigned)(ev >> 32));
+                if (lane < zc && zc + lane < 33) out[zc + lane] = e;
+                zc = min(2 * zc, 33);
+            }
+        }
+        if (lane == 0) {
+            out[40] = make_int2(jend, dmin);
+            out[41] = make_int2(min(zc, 33), 0);
+        }
+    }
     if (lane == 0) d.st2n[pidx] = tren;
 }
 
@@ -903,7 +999,8 @@ __device__ __forceinline__ void take_best(int best, int bestxy, int &bmin, int &
 
 struct ResPre {  // predictor-independent operands of one partition (role 1 needs all, role 0 the last two lines)
     int n2, n3, n2raw;
-    int2 e2[FER_ST2_CAP / 64];
+    int2 e2[FER_ST2_CAP / 64];  // a crowded partition: e2[0] = (J, Dmin), e2[1].x = distance-0 candidates listed
+    int2 z;                     // ... and the lane's distance-0 candidate
     int c3x, c3y, c3s;
     int su[5];
     SrcBlk sb;  // source block (wave-uniform)
@@ -914,6 +1011,7 @@ __device__ __forceinline__ void res_prefetch(const FerDev &d, int s, int gx, int
     const int mb = (gy >> 1) * d.mbw + (gx >> 1), part = (gy & 1) * 2 + (gx & 1);
     const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
     p.n2 = p.n3 = p.n2raw = 0;
+    p.z = make_int2(0, 0);
     p.c3x = p.c3y = p.c3s = 0;
 #pragma unroll
     for (int u = 0; u < FER_ST2_CAP / 64; u++) p.e2[u] = make_int2(0, 0);
@@ -924,6 +1022,11 @@ __device__ __forceinline__ void res_prefetch(const FerDev &d, int s, int gx, int
         const int2 *c2 = (const int2 *)(d.st2 + pidx * FER_ST2_CAP * 2);
 #pragma unroll
         for (int u = 0; u < FER_ST2_CAP / 64; u++) p.e2[u] = c2[u * 64 + lane];  // slots >= n2 hold stale data, masked later
+        p.z = p.e2[0];
+        if (p.n2raw > FER_ST2_CAP) {  // the summary of a crowded partition sits in slots 40 and 41 (wave-uniform)
+            p.e2[0] = c2[40];
+            p.e2[1] = c2[41];
+        }
         const int *c3 = d.st3 + pidx * 33 * 3;
         const int l3 = min(lane, 32);
         p.c3x = c3[l3 * 3];
@@ -1074,6 +1177,120 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
     return false;
 }
 
+// ---- stage 2 of a crowded partition: the winners are looked for AROUND THE PREDICTOR ----
+// The candidate set of the bucket walk is "every position p of the 280-diamond around the block whose 8x8 sum is
+// within J of the block's and whose two half sums are within 100" (J = the step at which the walk stopped), a position
+// of sum exactly su[0] counting twice (bucket su[0] is visited from both sides at j = 0), and the list wanted is the
+// 33 smallest by (metric, arrival), metric = (|p - (block + gen)|_1 + 4) * D(p), arrival = (j, side, tx, ty).  All of
+// that can be evaluated per POSITION from the plane-0 feature records, without the sorted order.  So the L1 rings
+// around the predictor are scanned outwards, members inserted into the running top-33; a ring at distance r can only
+// hold metrics >= (r + 4) * Dmin, Dmin = the smallest positive distance of the whole set (from k_me_walk), which ends
+// the scan as soon as that exceeds the 33rd best metric found.  Candidates of distance 0 have metric 0 for any
+// predictor: k_me_walk listed the first 33 of them in arrival order, they lead the list.  In a flat area the scan ends
+// after a handful of rings, where re-walking the buckets visits hundreds of thousands of records per partition.
+struct CList {
+    int m;         // metric of slot == lane
+    unsigned ak;   // arrival key j << 21 | side << 20 | (tx + 280) << 10 | (ty + 280), relative to the block
+    int xy;
+};
+__device__ __forceinline__ void cl_insert(CList &L, int lane, bool valid, int m, unsigned ak, int xy)
+{
+    // candidates of this batch that beat the 33rd entry, in any order: the list is ordered by (m, ak) itself
+    const int tm = lane_bcast(L.m, 32);
+    const unsigned tk = (unsigned)lane_bcast((int)L.ak, 32);
+    unsigned long long mask = __ballot(valid && (m < tm || (m == tm && ak < tk)));
+    while (mask) {
+        const int src = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const int cm = lane_bcast(m, src), cxy = lane_bcast(xy, src);
+        const unsigned ck = (unsigned)lane_bcast((int)ak, src);
+        const int pos = __popcll(__ballot(lane < 33 && (L.m < cm || (L.m == cm && L.ak < ck))));
+        if (pos < 33) {
+            const int um = FER_DPP(L.m, DPP_WAVE_SHR1), uxy = FER_DPP(L.xy, DPP_WAVE_SHR1);
+            const unsigned uk = (unsigned)FER_DPP((int)L.ak, DPP_WAVE_SHR1);
+            if (lane > pos && lane < 33) {
+                L.m = um;
+                L.ak = uk;
+                L.xy = uxy;
+            } else if (lane == pos) {
+                L.m = cm;
+                L.ak = ck;
+                L.xy = cxy;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void resolve_crowded(const FerDev &d, int s, int sx, int sy, int lane, const ResPre &P, int genx, int geny,
+                                                WList &L2)
+{
+    const int W = d.W, H = d.H;
+    const uint16_t *F0 = d.feat0 + (size_t)s * 6 * d.ysz;
+    const SuPk sp = su_pack(P.su);
+    const int J = P.e2[0].x, dmin = P.e2[0].y, zc = P.e2[1].x;  // summary of k_me_walk (slots 40, 41 of the list)
+    CList L;
+    L.m = INF_M;
+    L.ak = 0xffffffffu;
+    L.xy = 0;
+    if (lane < zc) {  // the candidates of distance 0, already in arrival order (all of j = 0, side 0 first)
+        const int rel = P.z.x;
+        const int tx = rel >> 16, ty = (int)(short)(rel & 0xffff);
+        L.m = 0;
+        L.ak = (unsigned)lane;  // only their order matters: nothing else has metric 0
+        L.xy = pack_xy(tx * 4, ty * 4);
+    }
+    if (zc < 33 && dmin != 0x7fffffff) {
+        const int cx = sx + genx, cy = sy + geny;  // the ring centre, picture coordinates
+        const int rmax = 2 * 280 + iabs(genx) + iabs(geny);  // beyond, no position of the diamond is left
+        int done_r = -1;  // rings 0 .. done_r are complete
+        for (int k0 = 0;; k0 += 64) {
+            // position k of the outward enumeration: ring r = the largest r with 2 r (r - 1) + 1 <= k (ring 0 = {k = 0})
+            const int k = k0 + lane;
+            int r = 0, i = 0;
+            if (k > 0) {
+                r = (int)((1.0f + __fsqrt_rn((float)(2 * k - 1))) * 0.5f);
+                while (2 * r * (r - 1) + 1 > k) r--;
+                while (2 * (r + 1) * r + 1 <= k) r++;
+                i = k - (2 * r * (r - 1) + 1);  // 0 .. 4r - 1 along the ring
+            }
+            int dx = 0, dy = 0;
+            if (r > 0) {
+                const int q = i / r, t = i - q * r;
+                dx = q == 0 ? r - t : (q == 1 ? -t : (q == 2 ? t - r : t));
+                dy = q == 0 ? t : (q == 1 ? r - t : (q == 2 ? -t : t - r));
+            }
+            const int px = cx + dx, py = cy + dy;
+            const bool inpic = px >= 0 && px < W && py >= 0 && py < H;
+            const uint32_t *rec = (const uint32_t *)(F0 + ((size_t)iclamp(py, 0, H - 1) * W + iclamp(px, 0, W - 1)) * 6);
+            const uint32_t a = rec[0], b = rec[1], c = rec[2];
+            const int kk0 = (int)(a & 0xffffu), kk1 = (int)(a >> 16), kk2 = (int)(b & 0xffffu);
+            const int j = iabs(kk0 - P.su[0]);
+            const int tx = px - sx, ty = py - sy;
+            const bool member = inpic && j <= J && iabs(tx) + iabs(ty) < 280 && iabs(kk1 - P.su[1]) < 100 && iabs(kk2 - P.su[2]) < 100;
+            const int D = feat_dist_w(a, b, c, sp);
+            const bool take = member && D > 0;  // distance 0 is in the list already
+            const int m = (r + 4) * D;
+            const int side = kk0 > P.su[0] ? 1 : 0;
+            const unsigned akey = ((unsigned)j << 21) | ((unsigned)(tx + 280) << 10) | (unsigned)(ty + 280);
+            const int xy = pack_xy(tx * 4, ty * 4);
+            cl_insert(L, lane, take, m, akey | ((unsigned)side << 20), xy);
+            if (__any(take && j == 0)) cl_insert(L, lane, take && j == 0, m, akey | (1u << 20), xy);  // the second visit of bucket su[0]
+            // rings complete after this batch: all k < k0 + 64
+            {
+                int rr = (int)((1.0f + __fsqrt_rn((float)(2 * (k0 + 64) - 1))) * 0.5f);
+                while (2 * rr * (rr - 1) + 1 > k0 + 64) rr--;
+                while (2 * (rr + 1) * rr + 1 <= k0 + 64) rr++;
+                done_r = rr - 1;  // ring rr has started at or before position k0 + 64, rings below it are complete
+            }
+            const int t33 = lane_bcast(L.m, 32);
+            if (done_r >= rmax) break;
+            if (t33 < INF_M && (long long)(done_r + 1 + 4) * dmin > (long long)t33) break;
+        }
+    }
+    L2.m = L.m;
+    L2.xy = L.xy;
+}
+
 // role 1: stage 2 (K = 33 of the precomputed candidate set, weighted by the distance to the predictor)
 // and stage 3 (precomputed survivors): best (key, vector) of each
 template <int WIN>
@@ -1091,16 +1308,20 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
     predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
     const int genx = mvpx >> 2, geny = mvpy >> 2;
     WList L2;
-    if (P.n2raw > FER_ST2_CAP) {
-        // more candidates than k_me_walk keeps (flat areas): walk the buckets again, now that the predictor is known,
-        // through an exact running top-33 (ordered insertion = the reference's own list update)
+    if (P.n2raw > FER_ST2_CAP && d.zero_cnt[s] == 0) {
+        resolve_crowded(d, s, sx, sy, lane, P, genx, geny, L2);
+    } else if (P.n2raw > FER_ST2_CAP) {
+        // crowded AND the reference's mis-filed bucket layout (black areas): walk the buckets again, now that the
+        // predictor is known, through an exact running top-33 (ordered insertion = the reference's own list update)
         L2.m = INF_M;
         L2.xy = 0;
         const SuPk sp = su_pack(P.su);
-        walk_buckets(d, s, P.su, sp, sx, sy, lane, (uint32_t *)sel_lds, [&](bool ok, int rank, int rel, int D) {
+        int jx;
+        walk_buckets(d, s, P.su, sp, sx, sy, lane, (uint32_t *)sel_lds, jx, [&](bool ok, int rank, int rel, int D, uint32_t) {
             (void)rank;
             int tx = rel >> 16, ty = (int)(short)(rel & 0xffff);
             wl_insert(L2, 33, lane, ok, (iabs(tx - genx) + iabs(ty - geny) + 4) * D, pack_xy(tx * 4, ty * 4));
+            return false;
         });
     } else {
         int m2[FER_ST2_CAP / 64];
