@@ -27,6 +27,7 @@
 #define FER_IP_R 16
 #define FER_IP_T 4
 #define FER_IP_B 12
+#define FER_BRANGE_MIN 1024  // buckets with more positions than this get feature ranges (FerDev.brange)
 #define FER_ST2_CAP 384  // stage-2 candidates kept per 8x8 partition
 #define FER_LEVELS 400   // int16 per MB: luma 16x16, dc16 16, cdc 2x4, cac 2x4x15
 #define FER_LV_DC16 256
@@ -60,8 +61,8 @@ struct FerDev {
     uint32_t *kol2;      // [S*16384*kt + 1]
     int kt, ktw_shift;
     // per bucket (8x8 sum) the ranges of the other four sums over its positions: [S][16384][8] = max of k1..k4, then max of
-    // 65535 - k1..k4 (so that one atomicMax and a zero fill serve both ends); 0 / 0 = empty bucket.  Lower bounds of the
-    // feature distance for crowded partitions (k_me_walk).
+    // 65535 - k1..k4 (so that one atomicMax and a zero fill serve both ends), for buckets of more than FER_BRANGE_MIN
+    // positions; all zero = no ranges.  Lower bounds of the feature distance for crowded partitions (k_me_walk).
     uint32_t *brange;
     int *zero_cnt;       // [S] positions of the reference picture whose 8x8 sum is 0 (see "bucket 0" in k_sort_finish)
     // per-MB side information (a20)

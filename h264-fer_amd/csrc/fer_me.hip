@@ -887,23 +887,24 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
         bool zeros_possible = false;
         {
             const uint32_t *brs = d.brange + (size_t)s * 16384 * 8;
+            const uint32_t *kol2p = d.kol2 + (size_t)s * 16384 * d.kt;
             for (int b0 = -jend; b0 <= jend; b0 += 64) {
                 const int dj = b0 + lane;
                 const int a = su[0] + dj;
                 int lb = 0x7fffffff;
-                if (dj <= jend && a >= 0 && a < 16384) {
+                if (dj <= jend && a >= 0 && a < 16384 && kol2p[(size_t)(a + 1) * d.kt] != kol2p[(size_t)a * d.kt]) {  // a bucket with positions
                     const uint4 hi = *(const uint4 *)(brs + (size_t)a * 8), lo = *(const uint4 *)(brs + (size_t)a * 8 + 4);
                     const uint32_t h[4] = {hi.x, hi.y, hi.z, hi.w}, l[4] = {lo.x, lo.y, lo.z, lo.w};
-                    if (l[0] != 0) {  // the bucket holds something
-                        lb = iabs(dj);
+                    lb = iabs(dj);
+                    if (l[0] != 0) {  // ... and ranges (a large bucket); a small one is only known to be |dj| away
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             const int kmin = 65535 - (int)l[k], kmax = (int)h[k];
                             const int s1 = su[k + 1], s2 = su[k + 1] + dj;  // |s_k - k_k| and |(s_0 - s_k) - (a - k_k)| = |k_k - (s_k + dj)|
                             lb += max(max(kmin - s1, s1 - kmax), 0) + max(max(kmin - s2, s2 - kmax), 0);
                         }
-                        if (dj == 0 && lb == 0) zeros_possible = true;
                     }
+                    if (dj == 0 && lb == 0) zeros_possible = true;
                 }
                 dmin = min(dmin, lb);
             }

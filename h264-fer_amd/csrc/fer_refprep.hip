@@ -468,38 +468,6 @@ __global__ __launch_bounds__(256) void k_sort_index(FerDev d, const uint16_t *sk
     const size_t g0 = (size_t)s * n;
     int gap_lo = 0, gap_hi = 0;  // bins [gap_lo, gap_hi) get value gval
     uint32_t gval = 0;
-    if (d.zero_cnt[s] == 0) {
-        // ranges of k1..k4 per bucket (the records of a stream with sum-0 positions sit elsewhere: its crowded
-        // partitions take the exact slow path, which does not use the ranges)
-        const bool on = i < n;
-        const int key = on ? (int)skey[g0 + i] : -1;
-        uint32_t v[4] = {0, 0, 0, 0};
-        if (on) {
-            const uint32_t *r = d.sort_rec + (g0 + i) * 3;
-            const uint32_t r1 = r[1], r2 = r[2];
-            v[0] = r1 & 0xffffu;
-            v[1] = r1 >> 16;
-            v[2] = r2 & 0xffffu;
-            v[3] = r2 >> 16;
-        }
-        // the records are in key order: a wavefront sees one bucket, seldom a few; one set of atomics per bucket
-        unsigned long long todo = __ballot(on);
-        while (todo) {
-            const int kcur = __builtin_amdgcn_readlane(key, __ffsll((long long)todo) - 1);
-            const bool mine = on && key == kcur;
-            todo &= ~__ballot(mine);
-            uint32_t *br = d.brange + ((size_t)s * 16384 + (size_t)kcur) * 8;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int hi = wave_max(mine ? (int)v[k] : 0), lo = wave_max(mine ? 65535 - (int)v[k] : 0);
-                if ((threadIdx.x & 63) == 0) {
-                    // thousands of wavefronts share a crowded bucket: only one that widens the range touches it
-                    if ((uint32_t)hi > __hip_atomic_load(&br[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&br[k], (uint32_t)hi);
-                    if ((uint32_t)lo > __hip_atomic_load(&br[4 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&br[4 + k], (uint32_t)lo);
-                }
-            }
-        }
-    }
     if (i < n) {
         const int bin = (int)skey[g0 + i] * d.kt + (int)((d.sort_pos[g0 + i] >> 16) >> d.ktw_shift);
         int prev = -1;
@@ -526,6 +494,49 @@ __global__ __launch_bounds__(256) void k_sort_index(FerDev d, const uint16_t *sk
             int lo = __shfl(gap_lo, src), hi = __shfl(gap_hi, src);
             uint32_t val = (uint32_t)__shfl((int)gval, src);
             for (int b = lo + (threadIdx.x & 63); b < hi; b += 64) kol2[b] = val;
+        }
+    }
+}
+
+// Ranges of the other four sums over the positions of a bucket, for the LARGE buckets only (more than
+// FER_BRANGE_MIN positions: flat areas).  k_me_walk bounds the feature distance of a crowded partition's candidates
+// with them; a bucket without ranges is simply unbounded there.  One thread per sorted record: the bucket's size comes
+// from the index, a wavefront usually sits inside one bucket and folds its 64 records into one set of atomics, which
+// it skips when the range already covers them.
+__global__ __launch_bounds__(256) void k_bucket_ranges(FerDev d, const uint16_t *skey)
+{
+    const int s = blockIdx.y;
+    if (d.hdr[s * 4 + 3] != 0 || d.zero_cnt[s] != 0) return;  // (a stream with sum-0 positions: its crowded partitions take the exact slow path)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = d.W * d.H;
+    const size_t g0 = (size_t)s * n;
+    const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * d.kt;
+    const bool in = i < n;
+    const int key = in ? (int)skey[g0 + i] : -1;
+    const bool on = in && kol2[(size_t)(key + 1) * d.kt] - kol2[(size_t)key * d.kt] > FER_BRANGE_MIN;
+    if (!__any(on)) return;
+    uint32_t v[4] = {0, 0, 0, 0};
+    if (on) {
+        const uint32_t *r = d.sort_rec + (g0 + i) * 3;
+        const uint32_t r1 = r[1], r2 = r[2];
+        v[0] = r1 & 0xffffu;
+        v[1] = r1 >> 16;
+        v[2] = r2 & 0xffffu;
+        v[3] = r2 >> 16;
+    }
+    unsigned long long todo = __ballot(on);
+    while (todo) {
+        const int kcur = __builtin_amdgcn_readlane(key, __ffsll((long long)todo) - 1);
+        const bool mine = on && key == kcur;
+        todo &= ~__ballot(mine);
+        uint32_t *br = d.brange + ((size_t)s * 16384 + (size_t)kcur) * 8;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int hi = wave_max(mine ? (int)v[k] : 0), lo = wave_max(mine ? 65535 - (int)v[k] : 0);
+            if ((threadIdx.x & 63) == 0) {
+                if ((uint32_t)hi > __hip_atomic_load(&br[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&br[k], (uint32_t)hi);
+                if ((uint32_t)lo > __hip_atomic_load(&br[4 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&br[4 + k], (uint32_t)lo);
+            }
         }
     }
 }
@@ -616,6 +627,7 @@ void fer_launch_sort_finish(const FerDev &d, FerSortTmp &t, hipStream_t st)
     const int n = d.W * d.H;
     hipMemsetAsync(d.brange, 0, (size_t)d.S * 16384 * 8 * sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_sort_index, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
+    hipLaunchKernelGGL(k_bucket_ranges, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
     hipLaunchKernelGGL(k_sort_quirk, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.rec_tmp);
 }
 
