@@ -658,7 +658,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
 // tbl = 128 dwords of LDS private to the calling wavefront.
 template <bool QUIRK, class SINK>
 __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int (&su)[5], const SuPk &sp, int sx, int sy, int lane,
-                                              uint32_t *tbl, int &jend, SINK sink)
+                                              uint32_t *tbl, int halt_cnt, int &jend, SINK sink)
 {
     int tren = 0;
     jend = 180;  // last step whose buckets belong to the candidate set
@@ -713,7 +713,7 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
         }
         const bool halt = sink(ok, rank, (int)pk_sub16(r0, sxy), (int)D, info);
         tren += __popcll(mk);
-        return halt;
+        return halt || tren > halt_cnt;  // the sink has what it wanted, or the caller only asked whether the count passes halt_cnt
     };
     // runs the nb <= 62 batches whose descriptors sit one per lane (lanes >= nb: empty batches); true = the walk is over
     auto run_table = [&](uint32_t dstart, uint32_t dinfo, int nb) -> bool {
@@ -829,12 +829,12 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
 
 template <class SINK>
 __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&su)[5], const SuPk &sp, int sx, int sy, int lane,
-                                            uint32_t *tbl, int &jend, SINK sink)
+                                            uint32_t *tbl, int halt_cnt, int &jend, SINK sink)
 {
     jend = 0;
     if (d.basic || FER_DBGF(d, 8)) return 0;
-    if (d.zero_cnt[s] > 0) return walk_buckets_q<true>(d, s, su, sp, sx, sy, lane, tbl, jend, sink);
-    return walk_buckets_q<false>(d, s, su, sp, sx, sy, lane, tbl, jend, sink);
+    if (d.zero_cnt[s] > 0) return walk_buckets_q<true>(d, s, su, sp, sx, sy, lane, tbl, 0x7fffffff, jend, sink);  // (the exact slow path needs every candidate)
+    return walk_buckets_q<false>(d, s, su, sp, sx, sy, lane, tbl, halt_cnt, jend, sink);
 }
 
 // ------------------------------------------------------------------ k_me_walk
@@ -870,9 +870,9 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
     int jend;
     // more than FER_ST2_CAP candidates make the partition "crowded" (below): the count itself is not needed then, and
     // the step the stop test would fire in is the current one (the count is already past 128)
-    const int tren = walk_buckets(d, s, su, sp, sx, sy, lane, tbl, jend, [&](bool ok, int rank, int rel, int D, uint32_t) {
+    const int tren = walk_buckets(d, s, su, sp, sx, sy, lane, tbl, FER_ST2_CAP, jend, [&](bool ok, int rank, int rel, int D, uint32_t) {
         if (ok && rank < FER_ST2_CAP) out[rank] = make_int2(rel, D);
-        return __any(ok && rank >= FER_ST2_CAP) && d.zero_cnt[s] == 0;
+        return false;
     });
     if (tren > FER_ST2_CAP && d.zero_cnt[s] == 0) {
         // A crowded partition (flat areas: thousands of positions share a feature vector).  k_me_resolve will not go
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
             // half's, repeated.  (A scan that runs to the end also gives the exact smallest positive distance.)
             int j2, dpos = 0x7fffffff;
             bool complete = true;
-            walk_buckets(d, s, su, sp, sx, sy, lane, tbl, j2, [&](bool ok, int rank, int rel, int D, uint32_t info) {
+            walk_buckets(d, s, su, sp, sx, sy, lane, tbl, 0x7fffffff, j2, [&](bool ok, int rank, int rel, int D, uint32_t info) {
                 (void)rank;
                 if (jend == 0 && (info >> 31)) return true;
                 const bool z = ok && D == 0;
@@ -1318,7 +1318,7 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
         L2.xy = 0;
         const SuPk sp = su_pack(P.su);
         int jx;
-        walk_buckets(d, s, P.su, sp, sx, sy, lane, (uint32_t *)sel_lds, jx, [&](bool ok, int rank, int rel, int D, uint32_t) {
+        walk_buckets(d, s, P.su, sp, sx, sy, lane, (uint32_t *)sel_lds, 0x7fffffff, jx, [&](bool ok, int rank, int rel, int D, uint32_t) {
             (void)rank;
             int tx = rel >> 16, ty = (int)(short)(rel & 0xffff);
             wl_insert(L2, 33, lane, ok, (iabs(tx - genx) + iabs(ty - geny) + 4) * D, pack_xy(tx * 4, ty * 4));
