@@ -129,14 +129,26 @@ int inputWidth = 0, inputHeight = 0;
 static ferhip_y4m *g_in = nullptr;
 static bool g_out_header_done = false;
 
+// The reference allocates `frame` at SPS time (init_h264_structures[_encoder], F/h264_globals.cpp:224-297) and never
+// frees it.  A host may also have pointed `frame` at buffers of its own: only planes allocated here are ever released.
+static unsigned char *g_own[3] = {nullptr, nullptr, nullptr};
 static void frame_alloc_if_needed()
 {
-    // the reference allocates `frame` at SPS time (init_h264_structures[_encoder], F/h264_globals.cpp:224-297)
-    if (!frame.L) frame.L = new unsigned char[(size_t)frame.Lwidth * frame.Lheight];
-    if (!frame.C[0]) frame.C[0] = new unsigned char[(size_t)frame.Cwidth * frame.Cheight];
-    if (!frame.C[1]) frame.C[1] = new unsigned char[(size_t)frame.Cwidth * frame.Cheight];
+    if (!frame.L) frame.L = g_own[0] = new unsigned char[(size_t)frame.Lwidth * frame.Lheight];
+    if (!frame.C[0]) frame.C[0] = g_own[1] = new unsigned char[(size_t)frame.Cwidth * frame.Cheight];
+    if (!frame.C[1]) frame.C[1] = g_own[2] = new unsigned char[(size_t)frame.Cwidth * frame.Cheight];
 }
 extern "C" void ferhip_legacy_frame_alloc(void) { frame_alloc_if_needed(); }
+// a new picture size: drop the planes (the library's own are freed, a host's are merely forgotten)
+extern "C" void ferhip_legacy_frame_drop(void)
+{
+    unsigned char **pl[3] = {&frame.L, &frame.C[0], &frame.C[1]};
+    for (int i = 0; i < 3; i++) {
+        if (*pl[i] && *pl[i] == g_own[i]) delete[] g_own[i];
+        g_own[i] = nullptr;
+        *pl[i] = nullptr;
+    }
+}
 
 extern "C" void LoadY4MHeader(void)
 {

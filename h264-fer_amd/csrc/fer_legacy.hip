@@ -24,6 +24,7 @@ static ferhip_ctx *g_ctx = nullptr;
 static int g_have_dpb = 0;
 static ferhip_dec *g_dec = nullptr;
 extern "C" void ferhip_legacy_frame_alloc(void);
+extern "C" void ferhip_legacy_frame_drop(void);
 
 static int ensure_ctx()
 {
@@ -117,12 +118,7 @@ extern "C" void RBSP_decode(NALunit nal_unit)
         return;
     }
     if (type == 7) {  // fill_sps + init_h264_structures: `frame` takes the picture size
-        if (frame.L && (frame.Lwidth != W || frame.Lheight != H)) {
-            delete[] frame.L;
-            delete[] frame.C[0];
-            delete[] frame.C[1];
-            frame.L = frame.C[0] = frame.C[1] = nullptr;
-        }
+        if (frame.L && (frame.Lwidth != W || frame.Lheight != H)) ferhip_legacy_frame_drop();
         frame.Lwidth = W;
         frame.Lheight = H;
         frame.Cwidth = W >> 1;

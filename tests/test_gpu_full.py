@@ -232,13 +232,13 @@ def test_bad_arguments_are_rejected(pkg):
         pkg.FerHip(176, 144, 0)          # no streams
 
 
-@pytest.mark.parametrize("W,H,T,qp,window,noise", [(176, 144, 5, 12, 16, 2), (176, 144, 4, 12, 32, 0), (1920, 1072, 3, 12, 32, 2)])
+@pytest.mark.parametrize("W,H,T,qp,window,noise", [(176, 144, 5, 12, 16, 2), (176, 144, 4, 12, 32, 0), (1920, 1072, 2, 12, 32, 2)])
 def test_basic_inter_encoding_matches_oracle(pkg, fo, W, H, T, qp, window, noise):
     """BasicInterEncoding = 1 (F/moestimation.cpp:394-397,470): the exhaustive pass whose vectors the reference
     discards leaves only brojTipova behind; stages 2 and 3 of the feature search are skipped.  Bitstream,
     reconstruction and the counters (P_Skip counted twice, the discarded pass's own 16x16 / 8x8 verdicts) must be
     the oracle's."""
-    S = 2
+    S = 2 if W < 1000 else 1   # (the oracle's literal exhaustive pass takes a minute per 1080p P picture)
     # noise 0 = still content: P_Skip macroblocks
     frames = np.stack([np.stack([pkg.gen_frame(W, H, t if noise else 0, 99 + s, noise) for s in range(S)]) for t in range(T)])
     g = pkg.FerHip(W, H, S, qp=qp, window=window, maxdiff=3, intra_every=30, basic=1)
@@ -310,6 +310,10 @@ def test_legacy_global_seam_matches_oracle(pkg, fo):
     ref, ref_rec = o.encode_stream(frames)
     assert bytes(out) == ref
     assert np.array_equal(np.stack(recs), ref_rec)
+    # `frame` pointed at buffers of this test: do not leave them behind for the library to write into
+    frame.L = None
+    frame.C[0] = None
+    frame.C[1] = None
 
 
 def _oracle_decode(fo, stream):
@@ -390,6 +394,14 @@ def test_legacy_rbsp_decode_seam(pkg, tmp_path):
         _fields_ = [("forbidden_zero_bit", C.c_ubyte), ("nal_ref_idc", C.c_uint), ("nal_unit_type", C.c_uint),
                     ("NumBytesInRBSP", C.c_uint), ("rbsp_byte", C.POINTER(C.c_ubyte))]
 
+    class Frame(C.Structure):
+        _fields_ = [("Lwidth", C.c_int), ("Lheight", C.c_int), ("Cwidth", C.c_int), ("Cheight", C.c_int),
+                    ("L", C.POINTER(C.c_ubyte)), ("C", C.POINTER(C.c_ubyte) * 2)]
+
+    frame = Frame.in_dll(lib, "frame")   # the SPS call sizes and allocates it, as in the reference
+    frame.L = None
+    frame.C[0] = None
+    frame.C[1] = None
     lib.RBSP_decode.argtypes = [NALunit]
     lib.RBSP_decode.restype = None
     stream = (GOLD / "drugi.264").read_bytes()
