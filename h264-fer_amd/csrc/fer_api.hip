@@ -1111,7 +1111,9 @@ struct HostBR {
 struct DecHdr {
     int have_sps, have_pps, W, H, log2_max_frame_num, poc_type, log2_max_poc_lsb;
     int pic_init_qp, chroma_qp_offset, deblock_ctl, constrained_intra;
-    int mod_flag;
+    // slice-header state the reference keeps in globals between slices: the active reference count is only ever set
+    // by an override (never reset to the PPS default), the list-modification flag and its entry count only by P slices
+    int nref_active_minus1, mod_flag, mod_copies;
 };
 
 // seq_parameter_set_rbsp, F/headers_and_parameter_sets.cpp:398-470.  Returns 0, or FERHIP_E_UNSUP for syntax the
@@ -1178,11 +1180,22 @@ static int dec_parse_slice_header(DecHdr &h, const uint8_t *rbsp, size_t n, int 
     r.bits(h.log2_max_poc_lsb);
     if (st == 0 || st == 1 || st == 3) {
         override_flag = (int)r.bits(1);
-        if (override_flag && r.ue() > 0) return FERHIP_E_UNSUP;  // more than one reference index
+        if (override_flag) h.nref_active_minus1 = (int)r.ue();  // only tells the macroblock layer whether ref_idx is coded
     }
-    if (st != 2 && st != 4) {
+    if (st != 2 && st != 4) {  // ref_pic_list_modification (F/headers_and_parameter_sets.cpp:196-215)
         h.mod_flag = (int)r.bits(1);
-        if (h.mod_flag) return FERHIP_E_UNSUP;  // reference list modification
+        h.mod_copies = 0;
+        if (h.mod_flag) {
+            unsigned idc;
+            int guard = 0;
+            do {
+                idc = r.ue();
+                if (idc <= 2) {
+                    r.ue();
+                    h.mod_copies++;
+                }
+            } while (idc != 3 && ++guard < 64 && r.pos < n * 8);
+        }
     }
     if (ref_idc != 0) {
         if (nal_type == 5) {
@@ -1208,7 +1221,9 @@ static int dec_parse_slice_header(DecHdr &h, const uint8_t *rbsp, size_t n, int 
     if (st != 0 && st != 2) return FERHIP_E_UNSUP;
     info[0] = (uint32_t)n;
     info[1] = (uint32_t)r.pos;
-    info[2] = (uint32_t)st;
+    // slice type | ref_idx coded in sub-macroblock prediction (the reference tests the override FLAG there,
+    // F/rbsp_decoding.cpp:156) << 8 | active reference count - 1 (what it tests in mb_pred, :217) << 16
+    info[2] = (uint32_t)st | ((uint32_t)(override_flag ? 1 : 0) << 8) | ((uint32_t)std::min(h.nref_active_minus1, 255) << 16);
     info[3] = (uint32_t)qp;
     return 0;
 }
@@ -1367,7 +1382,12 @@ struct DecSession {
     uint32_t *d_info = nullptr;
     size_t TWmax = 0, nm = 0, fsz = 0;
     std::vector<uint32_t> info, hdr;
-    std::vector<char> anyP, anyAny;
+    std::vector<char> anyP, anyAny, keep;
+    // A picture whose slice carries an empty reference-list modification is NOT stored as the reference picture
+    // (modificationProcess, F/ref_frames.cpp:130-183): the stream's last decoded picture (what `frame` holds, what a
+    // slice that ends early leaves in place) then differs from its reference picture and waits in `hold`.
+    uint8_t *hold = nullptr;
+    std::vector<char> held;
     double t_pack = 0, t_parse = 0, t_recon = 0;
 };
 
@@ -1381,6 +1401,8 @@ static void dec_session_close(DecSession &ss)
     }
     dec_arena_release(ss.ar);
     ss.ar = nullptr;
+    if (ss.hold) hipFree(ss.hold);
+    ss.hold = nullptr;
     if (ss.c) ferhip_destroy(ss.c);
     ss.c = nullptr;
 }
@@ -1451,6 +1473,19 @@ static int dec_session_open(DecSession &ss, int W, int H, int S, size_t T, bool 
     B.cac_out = (int16_t *)wmalloc(sizes[14]);
     ss.d_info = (uint32_t *)wmalloc(sizes[15]);
     ss.hs.assign(S, DecHdr{});
+    ss.held.assign(S, 0);
+    return 0;
+}
+
+// the three planes of stream s from one plane-major picture set to another (same stream order)
+static int dec_copy_stream(ferhip_ctx *c, uint8_t *dst, const uint8_t *src, int s)
+{
+    const FerDev &d = c->d;
+    const size_t S = (size_t)d.S;
+    const size_t off[3] = {(size_t)s * d.ysz, S * d.ysz + (size_t)s * d.csz, S * (d.ysz + d.csz) + (size_t)s * d.csz};
+    const size_t len[3] = {d.ysz, d.csz, d.csz};
+    for (int k = 0; k < 3; k++)
+        if (hipMemcpyAsync(dst + off[k], src + off[k], len[k], hipMemcpyDeviceToDevice, c->st) != hipSuccess) return FERHIP_E_HIP;
     return 0;
 }
 
@@ -1470,6 +1505,7 @@ static int dec_session_window(DecSession &ss, const std::vector<std::vector<cons
     ss.hdr.assign(TW * S * 4, 0);
     ss.anyP.assign(TW, 0);
     ss.anyAny.assign(TW, 0);
+    ss.keep.assign(TW * S, 1);
     // slice headers and the offsets of the slices in the window's RBSP buffer
     size_t total = 0;
     for (size_t t = 0; t < TW; t++)
@@ -1488,9 +1524,10 @@ static int dec_session_window(DecSession &ss, const std::vector<std::vector<cons
             // what the kernels need of this stream's PPS travels with the picture
             hd[0] = (uint32_t)ss.hs[s].chroma_qp_offset;
             hd[1] = (uint32_t)ss.hs[s].constrained_intra;
-            hd[3] = in[2];
-            ss.anyP[t] |= in[2] == 0;
+            hd[3] = in[2] & 255u;
+            ss.anyP[t] |= (in[2] & 255u) == 0;
             ss.anyAny[t] = 1;
+            ss.keep[t * S + s] = !ss.hs[s].mod_flag || ss.hs[s].mod_copies > 0;
         }
     if (total + 64 > ar->rbsp_cap) {
         if (ar->d_rbsp) hipFree(ar->d_rbsp);
@@ -1548,6 +1585,8 @@ static int dec_session_window(DecSession &ss, const std::vector<std::vector<cons
         if (hipMemcpyAsync(c->planes[c->cur_set], c->planes[c->cur_set ^ 1], d.ysz * 3 / 2 * S, hipMemcpyDeviceToDevice, c->st) !=
             hipSuccess)
             return FERHIP_E_HIP;
+        for (int s = 0; s < S; s++)  // ... which, for a stream whose last picture was not stored as reference, waits in `hold`
+            if (ss.held[s] && dec_copy_stream(c, c->planes[c->cur_set], ss.hold, s)) return FERHIP_E_HIP;
         FerDev ds = d;  // this picture's slice of the window
         const size_t o = t * nm;
         ds.mb_type = B.mb_type + o;
@@ -1567,6 +1606,22 @@ static int dec_session_window(DecSession &ss, const std::vector<std::vector<cons
         if (out) {
             int rc = ferhip_get_recon(c, out + (t0 + t) * S * ss.fsz, 1);
             if (rc) return rc;
+        }
+        for (int s = 0; s < S; s++) {
+            if (t0 + t >= slices[s].size()) continue;
+            if (!ss.keep[t * S + s]) {
+                // not stored: the picture moves to `hold`, the stream's reference picture (still intact in the other
+                // set) moves back into the reference set
+                if (!ss.hold) {
+                    if (hipMalloc((void **)&ss.hold, d.ysz * 3 / 2 * S + 256) != hipSuccess) return FERHIP_E_HIP;
+                }
+                if (dec_copy_stream(c, ss.hold, c->planes[c->cur_set ^ 1], s) ||
+                    dec_copy_stream(c, c->planes[c->cur_set ^ 1], c->planes[c->cur_set], s))
+                    return FERHIP_E_HIP;
+                ss.held[s] = 1;
+            } else {
+                ss.held[s] = 0;
+            }
         }
         if (pictures)
             for (int s = 0; s < S; s++)
@@ -1717,7 +1772,7 @@ extern "C" int ferhip_dec_nal(ferhip_dec *dc, int nal_unit_type, int nal_ref_idc
         slices[0].push_back(&nal);
         int rc = dec_session_window(dc->ss, slices, 0, 1, picture, nullptr);
         if (rc) return rc;
-        dc->h.mod_flag = dc->ss.hs[0].mod_flag;
+        dc->h = dc->ss.hs[0];  // the slice header leaves state behind (reference count override, list modification)
         dc->pictures++;
         if (got_picture) *got_picture = 1;
     }  // every other NAL unit type (SEI, AUD ...) is ignored, as in the reference

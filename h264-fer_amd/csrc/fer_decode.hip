@@ -92,6 +92,19 @@ __device__ __forceinline__ int db_se(DecBits &b)
     int v = (int)db_ue(b);
     return (v & 1) ? (v + 1) / 2 : -v / 2;
 }
+// te(v) as the reference reads it, whatever the range (F/expgolomb.cpp:156-178): an Exp-Golomb prefix and suffix;
+// a code number above 2 is returned as is, anything else (other than the single bit "1" = 0) is followed by one
+// more bit whose inverse is the value.  The bits consumed are what matters here -- the value is never used.
+__device__ __forceinline__ unsigned db_te(DecBits &b)
+{
+    unsigned w = db_peek(b, 24);
+    int z = w ? __clz((int)w) - 8 : 24;
+    db_skip(b, (unsigned)(z + 1));
+    if (z == 0) return 0;
+    unsigned x = db_bits(b, z);
+    if (x > 1) return (1u << z) - 1u + x;
+    return db_bit(b) ? 0u : 1u;
+}
 __device__ __forceinline__ bool db_more(const DecBits &b) { return (b.pos >> 3) + 1 < b.size; }
 
 // ---- decode tables: the code tables of F/residual_tables.cpp inverted once per process into direct
@@ -348,7 +361,7 @@ __device__ int dec_nC(const DecNb *row, int x, int y, bool luma, int blk, int pl
 }
 
 // P macroblock vectors: PredictMV + DeriveMVs (F/mode_pred.cpp:381-482), quadrant storage
-__device__ void dec_derive_mvs(const FerDev &d, short *mvs, const int *mbt, int mb, int type, const int mvd[4][2])
+__device__ void dec_derive_mvs(const FerDev &d, short *mvs, const int *mbt, int mb, int type, const int mvd[4][2], const int sub[4])
 {
     MvCtx c;
     c.mv = mvs;
@@ -376,7 +389,10 @@ __device__ void dec_derive_mvs(const FerDev &d, short *mvs, const int *mbt, int 
     int np = type == 0 ? 1 : (type <= 2 ? 2 : 4);
     for (int i = 0; i < np; i++) {
         int px, py;
-        predict_luma(c, i, px, py);
+        if (np == 4)
+            predict_luma_quadrant(c, i, sub, px, py);
+        else
+            predict_luma(c, i, px, py);
         px += mvd[i][0];
         py += mvd[i][1];
         // quadrants covered by partition i
@@ -461,7 +477,12 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
     // (bit position, window, QP) stays on the scalar unit
     const unsigned i_size = (unsigned)__builtin_amdgcn_readfirstlane((int)info[0]);
     const unsigned i_pos = (unsigned)__builtin_amdgcn_readfirstlane((int)info[1]);
-    const int stype = __builtin_amdgcn_readfirstlane((int)info[2]);
+    const int i_slice = __builtin_amdgcn_readfirstlane((int)info[2]);
+    const int stype = i_slice & 255;
+    // ref_idx_l0 is parsed and dropped (every prediction uses the one stored picture): in sub_mb_pred the reference
+    // reads it when the slice carried num_ref_idx_active_override_flag, in mb_pred when the active count left behind
+    // by the last override is > 1 (F/rbsp_decoding.cpp:156-161, :217-221)
+    const bool ref_sub = ((i_slice >> 8) & 1) != 0, ref_mb = (i_slice >> 16) > 0;
     const unsigned i_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)info[4]), i_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)info[5]);
     if (i_size == 0) {  // no picture for this stream at this step
         if (lane == 0) {
@@ -484,6 +505,7 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
     int cur = 0;
     bool more = true;
     int mvd[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    int sub[4] = {0, 0, 0, 0};
 #ifdef FER_PROBE
     long long tacc[4] = {0, 0, 0, 0}, tmark = wall_clock64();
 #define DP_MARK(k)                        \
@@ -504,7 +526,7 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
                 mbt[cur] = FER_P_SKIP;
                 if (lane == 0) row[cur % d.mbw].skip = 1;
                 for (int k = 0; k < 4; k++) mvd[k][0] = mvd[k][1] = 0;  // ClearMVD in PredictMV
-                dec_derive_mvs(d, mvs, mbt, cur, FER_P_SKIP, mvd);
+                dec_derive_mvs(d, mvs, mbt, cur, FER_P_SKIP, mvd, sub);
                 QPy = (QPy + mb_qp_delta + 52) % 52;
                 n_inherit += delta_known ? 0 : 1;
                 d.dec_qp[mbi] = (uint8_t)QPy;
@@ -535,18 +557,32 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
         int chroma_mode = 0;
         if (inter) {
             if (t == 3 || t == 4) {
-                int sub[4];
-                for (int i = 0; i < 4; i++) sub[i] = (int)db_ue(b);
-                if (sub[0] | sub[1] | sub[2] | sub[3]) {
-                    atomicOr(&d.status[s], FER_ERR_DEC_UNSUPPORTED);  // sub-8x8 partitions
+                bool badsub = false;
+                for (int i = 0; i < 4; i++) {
+                    sub[i] = (int)db_ue(b);
+                    badsub |= sub[i] > 3;
+                }
+                if (badsub) {
+                    atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
                     break;
                 }
+                if (ref_sub && t != FER_P_8x8ref0)
+                    for (int i = 0; i < 4; i++) db_te(b);
                 for (int i = 0; i < 4; i++) {
-                    mvd[i][0] = db_se(b);
-                    mvd[i][1] = db_se(b);
+                    // sub-partitions: 8x8 1, 8x4 2, 4x8 2, 4x4 4 vector differences, of which DeriveMVs keeps the first
+                    const int nsub = sub[i] == 0 ? 1 : (sub[i] == 3 ? 4 : 2);
+                    for (int j = 0; j < nsub; j++) {
+                        int dx = db_se(b), dy = db_se(b);
+                        if (j == 0) {
+                            mvd[i][0] = dx;
+                            mvd[i][1] = dy;
+                        }
+                    }
                 }
             } else {
                 int np = t == 0 ? 1 : 2;
+                if (ref_mb)
+                    for (int i = 0; i < np; i++) db_te(b);
                 for (int i = 0; i < np; i++) {
                     mvd[i][0] = db_se(b);
                     mvd[i][1] = db_se(b);
@@ -652,7 +688,7 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
         n_inherit += delta_known ? 0 : 1;
         d.dec_qp[mbi] = (uint8_t)QPy;
         if (inter) {
-            dec_derive_mvs(d, mvs, mbt, cur, t, mvd);
+            dec_derive_mvs(d, mvs, mbt, cur, t, mvd, sub);
         } else if (i4) {
             // getIntra4x4PredMode, F/intra.cpp:77-136
             for (int blk = 0; blk < 16; blk++) {

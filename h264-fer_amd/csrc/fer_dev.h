@@ -19,6 +19,7 @@
 #define FER_P_L0_16x16 0
 #define FER_P_16x8 1
 #define FER_P_8x16 2
+#define FER_P_8x8 3
 #define FER_P_8x8ref0 4
 #define FER_P_SKIP 31
 #define FER_MV_NA ((int)0x80808080u)

@@ -3,17 +3,25 @@
 // The reference's interEncoding (F/moestimation.cpp:392-585) is serial over macroblocks
 // because every search is centred on, and costed against, the predicted motion vector of
 // the partition (F/mode_pred.cpp:252-371).  The work is split here into
-//   k_me_pre      neighbour-independent: per 8x8 partition the five box sums of the source
-//                 block, the complete stage-3 search (wide integer + local quarter-pel window
-//                 around 0, top-33 list, SAD of each survivor) and the stage-2 candidate set
-//                 (bucket walk over the sum-sorted positions) -- one wavefront per partition;
-//   k_me_resolve  neighbour-dependent: P_Skip test, stage-1 search around the predictor,
-//                 re-ranking of the stage-2 candidates, final costs, partition merge, mvd,
-//                 final motion compensation and source snapping -- one wavefront per
-//                 macroblock, launched once per anti-diagonal x + 2y of the MB grid.
-// One wavefront owns one macroblock; the candidate list of MEstimation
-// (F/moestimation.cpp:254-296) lives one slot per lane and is updated by ballot-ordered
-// insertion, which reproduces the reference's arrival-order tie breaking exactly.
+//   k_me_pre      neighbour-independent, one wavefront per 8x8 partition (XCD-swizzled so that the partitions of a
+//                 picture region share one L2): the box sums of the source block, the complete stage-3 search
+//                 (wide integer window read from the plane-0 feature map + local quarter-pel window whose features
+//                 are computed on chip from the padded interpolated planes, local_metrics<R1>), its top-33 list
+//                 and the SAD of each survivor (lane per candidate, sad_keys<K>);
+//   k_me_walk     neighbour-independent, one wavefront per partition: the stage-2 bucket walk over the sum-sorted
+//                 16-byte feature records (walk_buckets_q, lane-held batch descriptor tables); partitions whose
+//                 candidate set overflows FER_ST2_CAP leave a summary (stop step, per-bucket lower bound, the
+//                 distance-0 list) instead of candidates;
+//   k_me_resolve  neighbour-dependent: P_Skip test, stage-1 search around the predictor, re-ranking of the stage-2
+//                 candidates (resolve_crowded: predictor-centred ring scan for overflowed partitions), final costs,
+//                 partition merge, mvd, final motion compensation and source snapping.  Persistent workgroups of
+//                 two wavefronts take (stream group, macroblock row) tickets from one queue per XCD and chain along
+//                 the row and to the row above through self-validating 64-bit words (chain64): no launch per
+//                 anti-diagonal, no grid-wide barrier.
+//   k_basic_stat  BasicInterEncoding = 1 only: the counters the discarded exhaustive pass leaves behind.
+// The candidate list of MEstimation (F/moestimation.cpp:254-296) is a selection problem here -- the K smallest by
+// (metric, arrival) -- solved without serial insertion (select_topk); the ballot-ordered insertion (wl_insert)
+// remains for the short serial tails.
 #include <stdlib.h>
 #include "fer_internal.h"
 #include "fer_mvpred.h"

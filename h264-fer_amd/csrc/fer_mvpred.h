@@ -93,7 +93,9 @@ __device__ __forceinline__ int med3(int a, int b, int c) { return max(min(a, b),
 
 // median rule of PredictMV_Luma (F/mode_pred.cpp:322-371) once A, B, C (C already replaced by D when
 // unavailable) are known: mx == FER_MV_NA marks an unavailable neighbour, ref is 0 or -1
-__device__ __forceinline__ void predict_core(int mx[3], int my[3], int ref[3], int &ox, int &oy)
+// Returns true when one of the three single-reference rules fired (the reference returns from PredictMV_Luma there,
+// before its sub-macroblock step, F/mode_pred.cpp:328-341).
+__device__ __forceinline__ bool predict_core(int mx[3], int my[3], int ref[3], int &ox, int &oy)
 {
     if (mx[0] == FER_MV_NA && mx[1] == FER_MV_NA) {
         mx[0] = 0;
@@ -118,30 +120,27 @@ __device__ __forceinline__ void predict_core(int mx[3], int my[3], int ref[3], i
     if (ref[0] == 0 && ref[1] != 0 && ref[2] != 0) {
         ox = mx[0];
         oy = my[0];
-        return;
+        return true;
     }
     if (ref[0] != 0 && ref[1] == 0 && ref[2] != 0) {
         ox = mx[1];
         oy = my[1];
-        return;
+        return true;
     }
     if (ref[0] != 0 && ref[1] != 0 && ref[2] == 0) {
         ox = mx[2];
         oy = my[2];
-        return;
+        return true;
     }
     ox = med3(mx[0], mx[1], mx[2]);
     oy = med3(my[0], my[1], my[2]);
+    return false;
 }
 
-// PredictMV_Luma, F/mode_pred.cpp:252-371, for reference index 0 everywhere
-__device__ void predict_luma(const MvCtx &c, int part, int &ox, int &oy)
+// neighbours A, B, C (D in place of an unavailable C) of the block whose top-left sample is (x, y) and whose
+// C neighbour sits at x + ppw (F/mode_pred.cpp:113-160, :258-296)
+__device__ __forceinline__ void gather_abc(const MvCtx &c, int x, int y, int ppw, int mx[3], int my[3], int ref[3])
 {
-    int t = c.type;
-    int pw = p_part_w(t), ph = p_part_h(t);
-    int x = (part % (16 / pw)) * pw, y = (part / (16 / pw)) * ph;
-    int ppw = (t == FER_P_8x8ref0 || t == FER_P_8x16) ? 8 : 16;
-    int mx[3], my[3], ref[3];
     bool val[4];
     int dxm = FER_MV_NA, dym = FER_MV_NA, dref = -1;
     for (int i = 0; i < 3; i++) {
@@ -153,11 +152,21 @@ __device__ void predict_luma(const MvCtx &c, int part, int &ox, int &oy)
     nbr_fetch(c, x + ppw, y - 1, val[2], mx[2], my[2], ref[2]);
     if (!val[2]) {
         nbr_fetch(c, x - 1, y - 1, val[3], dxm, dym, dref);
-        val[2] = val[3];
         mx[2] = dxm;
         my[2] = dym;
         ref[2] = dref;
     }
+}
+
+// PredictMV_Luma, F/mode_pred.cpp:252-371, for reference index 0 everywhere
+__device__ void predict_luma(const MvCtx &c, int part, int &ox, int &oy)
+{
+    int t = c.type;
+    int pw = p_part_w(t), ph = p_part_h(t);
+    int x = (part % (16 / pw)) * pw, y = (part / (16 / pw)) * ph;
+    int ppw = (t == FER_P_8x8 || t == FER_P_8x8ref0 || t == FER_P_8x16) ? 8 : 16;
+    int mx[3], my[3], ref[3];
+    gather_abc(c, x, y, ppw, mx, my, ref);
     if (t == FER_P_16x8 && part == 0 && mx[1] != FER_MV_NA && ref[1] == 0) {
         ox = mx[1];
         oy = my[1];
@@ -179,4 +188,29 @@ __device__ void predict_luma(const MvCtx &c, int part, int &ox, int &oy)
         return;
     }
     predict_core(mx, my, ref, ox, oy);
+}
+
+// PredictMV_Luma for a quadrant of P_8x8 / P_8x8ref0 whose sub-macroblock types are sub[0..3], as far as the
+// reference's DeriveMVs keeps it (F/mode_pred.cpp:163-249, :343-369, :476-481).  Every sub-partition vector ends up
+// overwritten by the quadrant's FIRST one, so only that one is derived:
+//   * the C neighbour sits 4 samples to the right for the 4-wide sub types (2, 3), 8 otherwise;
+//   * when one of the single-reference rules fires the reference has already returned;
+//   * otherwise PredictMV_LumaSubMB(part, 0) runs on the same neighbours with the directional rules keyed on
+//     sub_mb_type[subMbPartIdx] = sub[0] (quirk: not sub[part]): 8x4 takes B, 4x8 takes A, else the median again.
+__device__ void predict_luma_quadrant(const MvCtx &c, int part, const int sub[4], int &ox, int &oy)
+{
+    const int x = (part & 1) * 8, y = (part >> 1) * 8;
+    const int ppw = (sub[part] == 2 || sub[part] == 3) ? 4 : 8;
+    int mx[3], my[3], ref[3];
+    gather_abc(c, x, y, ppw, mx, my, ref);
+    const bool a_ok = mx[0] != FER_MV_NA && ref[0] == 0, b_ok = mx[1] != FER_MV_NA && ref[1] == 0;
+    const int ax = mx[0], ay = my[0], bx = mx[1], by = my[1];
+    if (predict_core(mx, my, ref, ox, oy)) return;
+    if (sub[0] == 1 && b_ok) {
+        ox = bx;
+        oy = by;
+    } else if (sub[0] == 2 && a_ok) {
+        ox = ax;
+        oy = ay;
+    }
 }

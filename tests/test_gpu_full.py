@@ -528,3 +528,56 @@ def test_gop_shards_over_two_contexts_equal_one_continuous_run(pkg, fo):
     whole, _ = o.encode_stream(frames)
     o.close()
     assert merged == whole
+
+
+def test_bench_ranks_shard_the_4k_gops(pkg):
+    """bench.py --gpus 2 starts two rank processes itself (gloo rehearsal: both ranks on this GPU), each rank encodes
+    its closed GOPs of the 64-picture 4K sequence with libferhip, the host merges the NAL units: the SHA-256 must be
+    that of ONE continuous oracle run (tests/golden/goldens.json, BASELINE configs[3])."""
+    import json
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--config", "4k", "--gpus", "2", "--dist-backend", "gloo",
+                          "--steps", "1", "--warmup", "0", "--cpu-frames", "0"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["output_check"]["ok"] is True and line["output_check"]["bytes"] == 54988382
+
+
+_F4_PLANS = {
+    # sub-8x8 partitions only
+    "sub_partitions": [dict(), dict(), dict()],
+    # ref_idx_l0 coded: override flag (sub_mb_pred) and the count it leaves behind (mb_pred of LATER slices too)
+    "ref_idx": [dict(override=True, active=1), dict(), dict(override=True, active=0), dict(), dict(override=True, active=3)],
+    # list modification: an empty one keeps the picture out of the reference slot, one with entries stores it
+    "list_modification": [dict(modification=[]), dict(), dict(modification=[(0, 0)]), dict(modification=[]),
+                          dict(modification=[]), dict(modification=[(1, 2), (2, 0)]), dict()],
+    # everything, and slices whose last macroblocks fall to the reference's more_rbsp_data() heuristic
+    "mixed": [dict(override=True, active=1, modification=[]), dict(early_end=True), dict(modification=[], early_end=True),
+              dict(override=True, active=0), dict(modification=[(0, 1)], mvd_range=12), dict(mvd_range=40, p_skip=0.05)],
+}
+
+
+@pytest.mark.parametrize("plan", sorted(_F4_PLANS))
+def test_decoder_sub_partitions_ref_idx_and_list_modification(pkg, fo, plan):
+    """Row f4: P slices the reference's encoder never writes but its decoder parses (tests/pslice_synth.py writes
+    them bit by bit after the IDR picture of a golden stream).  Batch decode (two different streams side by side, so
+    the not-stored pictures of one stream must not disturb the other) and NAL-by-NAL decode against the oracle."""
+    import pslice_synth as ps
+    base = (GOLD / "qcif_ippp_4f_qp12_w16.264").read_bytes()
+    a = ps.make_stream(pkg.split_nals, base, 7, _F4_PLANS[plan])
+    b = ps.make_stream(pkg.split_nals, base, 8, _F4_PLANS["sub_partitions"] + _F4_PLANS[plan][:3])
+    ra, rb = _oracle_decode(fo, a), _oracle_decode(fo, b)
+    assert ra.shape[0] == len(_F4_PLANS[plan]) + 1
+    assert (ra[1] != ra[0]).any()  # the P pictures do move
+    out, pics, W, H = pkg.decode_streams([a, b], max(ra.shape[0], rb.shape[0]))
+    assert pics == [ra.shape[0], rb.shape[0]]
+    for t in range(ra.shape[0]):
+        assert np.array_equal(out[t, 0], ra[t]), f"{plan}: picture {t}"
+    assert np.array_equal(out[:rb.shape[0], 1], rb)
+    d = pkg.Decoder()
+    got = [p for p in (d.nal(*pkg.unescape_nal(n)) for n in pkg.split_nals(a)) if p is not None]
+    d.close()
+    assert np.array_equal(np.stack(got), ra)

@@ -187,3 +187,17 @@ def test_legacy_file_io_names(pkg, tmp_path):
     want = b"YUV4MPEG2 C420jpeg W%d H%d F24:1 Ip A1:1\n" % (W, H) + b"".join(b"FRAME\n" + f.tobytes() for f in frames)
     assert dst.read_bytes() == want
     lib.ferhip_fileio_reset()
+
+
+def test_synthetic_p_slices_stay_in_sync_with_the_oracle_parser(pkg, fo):
+    """tests/pslice_synth.py (row f4's generator): with every mvd zero, whatever else the slices carry (sub-macroblock
+    types, te() reference indices, list modification, all-zero residual blocks), every P picture predicts the IDR
+    picture unchanged -- which it only does if generator and oracle parser agree on every bit."""
+    import pslice_synth as ps
+    base = (Path(__file__).parent / "golden" / "qcif_ippp_4f_qp12_w16.264").read_bytes()
+    plan = [dict(mvd_range=0), dict(override=True, active=1, mvd_range=0), dict(modification=[], mvd_range=0),
+            dict(mvd_range=0), dict(modification=[(0, 0)], mvd_range=0), dict(override=True, active=0, mvd_range=0)]
+    n, frames, _ = fo.decode_stream_md5(ps.make_stream(pkg.split_nals, base, 2, plan))
+    assert n == len(plan) + 1
+    for f in frames[1:]:
+        assert np.array_equal(f, frames[0])
