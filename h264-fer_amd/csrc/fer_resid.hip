@@ -7,18 +7,128 @@
 // source snapping of F/moestimation.cpp:529-584 -- because that needs exactly the prediction the residual
 // needs; the snapped source never goes back to memory (the reconstruction overwrites it anyway).
 //
-// One wavefront per macroblock.  All 64 lanes rebuild the prediction (motion compensation,
-// 4 luma + 2 chroma samples each) into LDS; then lane b < 16 owns luma block b, lanes 16..19
-// the Cb blocks and 20..23 the Cr blocks: difference, forward core, quantiser, zig-zag,
-// dequantiser, inverse core and clipped reconstruction all stay in that lane's registers.
-// The 2x2 chroma DC Hadamard crosses lanes with shuffles.
+// One wavefront per macroblock, four lanes per 4x4 block: lane = block * 4 + row holds one ROW of its block (four
+// samples in registers) from the prediction to the reconstruction.  The vertical half of every transform crosses the
+// four lanes of a quad with DPP quad_perm broadcasts, the horizontal half stays in the lane; all 64 lanes carry the 16
+// luma blocks at once, a second pass carries the 8 chroma blocks on lanes 0..31.  Prediction, source and
+// reconstruction move as one dword per lane; the levels are put in scan order in LDS and leave as one coalesced
+// 800-byte record.  The 2x2 chroma DC Hadamard runs on values read out of the lanes with v_readlane.
 #include "fer_internal.h"
 #include "fer_mvpred.h"
 
+// scan position of raster sample (row, x): the inverse of c_zz, one dword of four positions per row
+static __constant__ __align__(4) uint8_t c_izz[16] = {0, 1, 5, 6, 2, 4, 7, 12, 3, 8, 11, 13, 9, 10, 14, 15};
+
+#define QB0 0x00  // quad_perm broadcasts of lane 0..3 of the quad
+#define QB1 0x55
+#define QB2 0xAA
+#define QB3 0xFF
+
+struct RowQ {  // per-lane constants of a row of a 4x4 block
+    int row;
+    int k0, k1, k2, k3;  // vertical forward coefficients of this row (F/quantizationTransform.cpp:41-100)
+    int lq[4], ls[4];    // LevelQuantize / LevelScale of (row, x)
+};
+
+__device__ __forceinline__ RowQ rowq_make(int row, int qP)
+{
+    RowQ q;
+    q.row = row;
+    const bool r0 = row == 0, r1 = row == 1, r2 = row == 2;
+    q.k0 = (r0 || r2) ? 256 : (r1 ? 416 : 208);
+    q.k1 = r0 ? 256 : (r1 ? 208 : (r2 ? -256 : -416));
+    q.k2 = r0 ? 256 : (r1 ? -208 : (r2 ? -256 : 416));
+    q.k3 = (r0 || r2) ? 256 : (r1 ? -416 : -208);
+    const int m = qP % 6;
+    const int s_ee = level_scale(m, 0, 0), s_oo = level_scale(m, 1, 1), s_eo = level_scale(m, 0, 1);
+    const int q_ee = level_quant(m, 0, 0), q_oo = level_quant(m, 1, 1), q_eo = level_quant(m, 0, 1);
+    const bool odd = row & 1;
+    q.ls[0] = q.ls[2] = odd ? s_eo : s_ee;
+    q.ls[1] = q.ls[3] = odd ? s_oo : s_eo;
+    q.lq[0] = q.lq[2] = odd ? q_eo : q_ee;
+    q.lq[1] = q.lq[3] = odd ? q_oo : q_eo;
+    return q;
+}
+
+// a1 + a2 on the row r[0..3] (residual) of this lane: forward core (vertical across the quad, then horizontal) and
+// quantiser; c = levels of (row, x); returns the unquantised DC in dc0 (meaningful in row 0)
+__device__ __forceinline__ void fwd_row(const RowQ &q, const int r[4], int qP, bool keepDC, int c[4], int &dc0)
+{
+    int f[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const int h = r[x] == 0 ? 0 : r[x] * 64 - 32;
+        const int a = FER_DPP(h, QB0), b = FER_DPP(h, QB1), cc = FER_DPP(h, QB2), e = FER_DPP(h, QB3);
+        f[x] = (q.k0 * a + q.k1 * b + q.k2 * cc + q.k3 * e + 512) >> 10;
+    }
+    int t[4];
+    t[0] = (256 * (f[0] + f[1] + f[2] + f[3]) + 512) >> 10;
+    t[1] = (416 * f[0] + 208 * f[1] - 208 * f[2] - 416 * f[3] + 512) >> 10;
+    t[2] = (256 * (f[0] - f[1] - f[2] + f[3]) + 512) >> 10;
+    t[3] = (208 * f[0] - 416 * f[1] + 416 * f[2] - 208 * f[3] + 512) >> 10;
+    const int q6 = qP / 6;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const int v = qP < 24 ? ((t[x] * (1 << (4 - q6))) - (1 << (3 - q6))) * q.lq[x] : (t[x] >> (q6 - 4)) * q.lq[x];
+        c[x] = (v + 16384) >> 15;
+    }
+    dc0 = t[0];
+    if (keepDC && q.row == 0) c[0] = t[0];
+}
+
+// a6 + a7: dequantiser, inverse core (horizontal in the lane, then vertical across the quad) -> residual row
+__device__ __forceinline__ void inv_row(const RowQ &q, const int c[4], int qP, bool keepDC, int r[4])
+{
+    const int q6 = qP / 6;
+    int dq[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+        dq[x] = qP >= 24 ? (c[x] * q.ls[x]) * (1 << (q6 - 4)) : (c[x] * q.ls[x] + (1 << (3 - q6))) >> (4 - q6);
+    if (keepDC && q.row == 0) dq[0] = c[0];
+    const int e0 = dq[0] + dq[2], e1 = dq[0] - dq[2], e2 = (dq[1] >> 1) - dq[3], e3 = dq[1] + (dq[3] >> 1);
+    const int E[4] = {e0 + e3, e1 + e2, e1 - e2, e0 - e3};
+    const bool outer = q.row == 0 || q.row == 3, plus = q.row < 2;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const int a = FER_DPP(E[x], QB0), b = FER_DPP(E[x], QB1), cc = FER_DPP(E[x], QB2), e = FER_DPP(E[x], QB3);
+        const int g0 = a + cc, g1 = a - cc, g2 = (b >> 1) - e, g3 = b + (e >> 1);
+        const int u = outer ? g0 : g1, w = outer ? g3 : g2;
+        r[x] = ((plus ? u + w : u - w) + 32) >> 6;
+    }
+}
+
+__device__ __forceinline__ int quad_sum(int v)
+{
+    v += FER_DPP(v, DPP_QUAD_XOR1);
+    v += FER_DPP(v, DPP_QUAD_XOR2);
+    return v;
+}
+
+// four chroma samples (x .. x+3, y) of the block at (xPc, yPc), F/mocomp.cpp:80-110 (as mc_chroma, sample by sample)
+__device__ __forceinline__ void mc_chroma_row4(const uint8_t *__restrict__ R, int Wc, int Hc, int xPc, int yPc, int x, int y, int mvx,
+                                               int mvy, int out[4])
+{
+    const int by = (y >> 1) << 1, oy = y & 1;
+    const int cy = yPc + by + (mvy >> 3);
+    const int y0 = iclamp(cy + oy, 0, Hc - 1) * Wc, y1 = iclamp(cy + oy + 1, 0, Hc - 1) * Wc;
+    const int X = xPc + x + (mvx >> 3);  // x is a multiple of 4: sample k reads columns X + k and X + k + 1
+    int t[5], u[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int xc = iclamp(X + k, 0, Wc - 1);
+        t[k] = R[y0 + xc];
+        u[k] = R[y1 + xc];
+    }
+    const int xl = mvx & 7, yl = mvy & 7;
+    const int w00 = (8 - xl) * (8 - yl), w01 = xl * (8 - yl), w10 = (8 - xl) * yl, w11 = xl * yl;
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = (w00 * t[k] + w01 * t[k + 1] + w10 * u[k] + w11 * u[k + 1] + 32) >> 6;
+}
+
 __global__ __launch_bounds__(64) void k_p_resid(FerDev d)
 {
-    __shared__ uint8_t pL[16][16], pC[2][8][8];  // prediction
-    __shared__ uint8_t sL[16][16], sC[2][8][8];  // source after snapping
+    __shared__ __align__(16) int16_t lvs[FER_LEVELS];
+    __shared__ __align__(4) uint8_t tcs[24];
     const int lane = threadIdx.x;
     const int s = blockIdx.y, mb = blockIdx.x;
     if (d.hdr[s * 4 + 3] != 0) return;
@@ -26,19 +136,21 @@ __global__ __launch_bounds__(64) void k_p_resid(FerDev d)
     if (mbt[mb] == FER_P_SKIP) return;  // reconstructed by k_me_resolve
     const int W = d.W, H = d.H, Wc = d.Wc, Hc = d.Hc;
     uint8_t *Y = d.curY + (size_t)s * d.ysz;
-    uint8_t *C0 = d.curCb + (size_t)s * d.csz, *C1 = d.curCr + (size_t)s * d.csz;
     const uint8_t *RY = d.refY + (size_t)s * d.ysz;
-    const uint8_t *RC0 = d.refCb + (size_t)s * d.csz, *RC1 = d.refCr + (size_t)s * d.csz;
     const short *mvs = d.mv + (size_t)s * d.nmb * 8;
     const int xp = (mb % d.mbw) << 4, yp = (mb / d.mbw) << 4;
 
     // ---- partition merge and mvd under the final type (F/moestimation.cpp:529-560); every vector of the
     // picture is final here, so nothing below is read by another macroblock's decision
     int mvx[4], mvy[4];
+    {
+        const uint4 v = *(const uint4 *)(mvs + (size_t)mb * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        mvx[i] = mvs[(mb * 4 + i) * 2];
-        mvy[i] = mvs[(mb * 4 + i) * 2 + 1];
+        for (int i = 0; i < 4; i++) {
+            mvx[i] = (int)(short)(w[i] & 0xffff);
+            mvy[i] = (int)w[i] >> 16;
+        }
     }
     int type = FER_P_8x8ref0, stat = 4;
     if (mvx[0] == mvx[1] && mvx[0] == mvx[2] && mvx[0] == mvx[3] && mvy[0] == mvy[1] && mvy[0] == mvy[2] &&
@@ -52,6 +164,10 @@ __global__ __launch_bounds__(64) void k_p_resid(FerDev d)
         type = FER_P_8x16;
         stat = 3;
     }
+    auto mv_of = [&](int q, int &vx, int &vy) {  // vector of quadrant q (lane-dependent index: selects, no scratch)
+        vx = q == 0 ? mvx[0] : (q == 1 ? mvx[1] : (q == 2 ? mvx[2] : mvx[3]));
+        vy = q == 0 ? mvy[0] : (q == 1 ? mvy[1] : (q == 2 ? mvy[2] : mvy[3]));
+    };
     {
         MvCtx c;
         c.mv = mvs;
@@ -60,147 +176,144 @@ __global__ __launch_bounds__(64) void k_p_resid(FerDev d)
         c.cur = mb;
         c.type = type;
         c.coh = false;
-        int np = type == FER_P_L0_16x16 ? 1 : (type == FER_P_8x8ref0 ? 4 : 2);
-        int dvx[4] = {0, 0, 0, 0}, dvy[4] = {0, 0, 0, 0};
-        for (int i = 0; i < np; i++) {
-            int q = (type == FER_P_16x8 && i == 1) ? 2 : i;  // quadrant that carries partition i's vector
-            int px_, py_;
-            predict_luma(c, i, px_, py_);
-            dvx[i] = mvx[q] - px_;
-            dvy[i] = mvy[q] - py_;
-        }
+        const int np = type == FER_P_L0_16x16 ? 1 : (type == FER_P_8x8ref0 ? 4 : 2);
+        const int i = lane & 3;  // lane i < 4 derives partition i: one pass of the predictor for all of them
+        const int pi = i < np ? i : 0;
+        const int q = (type == FER_P_16x8 && pi == 1) ? 2 : pi;  // quadrant that carries partition i's vector
+        int px_, py_, qx, qy;
+        predict_luma(c, pi, px_, py_);
+        mv_of(q, qx, qy);
         if (lane < 4) {
-            short *o = d.mvd + ((size_t)s * d.nmb + mb) * 8;
-            o[lane * 2] = (short)dvx[lane];
-            o[lane * 2 + 1] = (short)dvy[lane];
+            const int dvx = i < np ? qx - px_ : 0, dvy = i < np ? qy - py_ : 0;
+            *(uint32_t *)(d.mvd + ((size_t)s * d.nmb + mb) * 8 + lane * 2) = ((uint32_t)dvx & 0xffffu) | ((uint32_t)dvy << 16);
         }
         if (lane == 0) {
             mbt[mb] = type;
             atomicAdd(&d.stats[s * 5 + stat], 1);
         }
     }
-    // ---- prediction and source snapping (F/moestimation.cpp:561-584): a source sample within MAXDIFF of the
-    // prediction is replaced by it
+    for (int i = lane; i < FER_LEVELS / 2; i += 64) ((uint32_t *)lvs)[i] = 0u;
+    __syncthreads();
+    const int row = lane & 3;
+    // ---- luma: prediction, source snapping (F/moestimation.cpp:561-584: a source sample within MAXDIFF of the
+    // prediction is replaced by it), residual, transform, levels, reconstruction
+    int MAXDIFF = d.maxdiff_set;
+    unsigned long long nz_l;
     {
-        int lx = (lane & 3) * 4, ly = lane >> 2;
+        const int blk = lane >> 2;
+        const int lx = c_bx[blk], ly = c_by[blk] + row;
+        uint8_t *dst = Y + (size_t)(yp + ly) * W + xp + lx;
+        const uint32_t sv = *(const uint32_t *)dst;
         int srcv[4];
-        uint32_t sv = *(const uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx);
 #pragma unroll
         for (int k = 0; k < 4; k++) srcv[k] = (sv >> (8 * k)) & 0xff;
-        int MAXDIFF = d.maxdiff_set;
         if (d.maxdiff_set == -1) {
             int mean = wave_sum(srcv[0] + srcv[1] + srcv[2] + srcv[3]) / 256;
             int dev = wave_sum(iabs(srcv[0] - mean) + iabs(srcv[1] - mean) + iabs(srcv[2] - mean) + iabs(srcv[3] - mean));
             MAXDIFF = dev / 256;
             if (MAXDIFF < 3) MAXDIFF = 3;
         }
-        int q = (ly >> 3) * 2 + (lx >> 3);
-        int pf[4];
-        mc_luma4(RY, ip_stream(d, s), W, H, xp, yp, lx, ly, mvx[q], mvy[q], pf);
+        int qx, qy, pf[4], r[4], c[4], dc0;
+        mv_of((ly >> 3) * 2 + (lx >> 3), qx, qy);
+        mc_luma4(RY, ip_stream(d, s), W, H, xp, yp, lx, ly, qx, qy, pf);
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = iabs(srcv[k] - pf[k]) < MAXDIFF ? 0 : srcv[k] - pf[k];
+        const RowQ q = rowq_make(row, d.qp);
+        fwd_row(q, r, d.qp, false, c, dc0);
+        const uint32_t z = ((const uint32_t *)c_izz)[row];
+        int cnt = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            lvs[blk * 16 + ((z >> (8 * x)) & 15u)] = (int16_t)c[x];
+            cnt += c[x] != 0;
+        }
+        cnt = quad_sum(cnt);
+        if (row == 0) tcs[blk] = (uint8_t)cnt;
+        nz_l = __ballot(cnt != 0);
+        inv_row(q, c, d.qp, false, r);
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) o |= (uint32_t)clip255(pf[k] + r[k]) << (8 * k);
+        *(uint32_t *)dst = o;
+    }
+    // ---- chroma on lanes 0..31 (32..63 shadow them and store nothing): plane = lane >> 4, block = (lane >> 2) & 3
+    unsigned long long nz_c, dcm;
+    {
+        const int l5 = lane & 31, cblk = l5 >> 2, pl = cblk >> 2, cb = cblk & 3;
+        const bool act = lane < 32;
+        const int x0 = (cb & 1) * 4, y0 = (cb >> 1) * 4 + row;
+        uint8_t *Cp = (pl ? d.curCr : d.curCb) + (size_t)s * d.csz;
+        const uint8_t *Rp = (pl ? d.refCr : d.refCb) + (size_t)s * d.csz;
+        uint8_t *dst = Cp + (size_t)(yp / 2 + y0) * Wc + xp / 2 + x0;
+        const uint32_t sv = *(const uint32_t *)dst;
+        int qx, qy, pf[4], r[4], c[4], dcraw;
+        mv_of(cb, qx, qy);
+        mc_chroma_row4(Rp, Wc, Hc, xp / 2, yp / 2, x0, y0, qx, qy, pf);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            pL[ly][lx + k] = (uint8_t)pf[k];
-            sL[ly][lx + k] = (uint8_t)(iabs(srcv[k] - pf[k]) < MAXDIFF ? pf[k] : srcv[k]);
+            const int sk = (sv >> (8 * k)) & 0xff;
+            r[k] = iabs(sk - pf[k]) <= MAXDIFF ? 0 : sk - pf[k];
         }
-        int cx = lane & 7, cy = lane >> 3;
-        int qc = (cy >> 2) * 2 + (cx >> 2);
-        size_t co = (size_t)(yp / 2 + cy) * Wc + xp / 2 + cx;
-        int pb = mc_chroma(RC0, Wc, Hc, xp / 2, yp / 2, cx, cy, mvx[qc], mvy[qc]);
-        int pr = mc_chroma(RC1, Wc, Hc, xp / 2, yp / 2, cx, cy, mvx[qc], mvy[qc]);
-        int sb = C0[co], sr = C1[co];
-        pC[0][cy][cx] = (uint8_t)pb;
-        pC[1][cy][cx] = (uint8_t)pr;
-        sC[0][cy][cx] = (uint8_t)(iabs(sb - pb) <= MAXDIFF ? pb : sb);
-        sC[1][cy][cx] = (uint8_t)(iabs(sr - pr) <= MAXDIFF ? pr : sr);
+        const RowQ q = rowq_make(row, d.qpc);
+        fwd_row(q, r, d.qpc, true, c, dcraw);
+        // chroma DC: 2x2 Hadamard + quantiser on the four DC values of each plane (row-0 lanes of its blocks)
+        int dcq, dcdeq;
+        {
+            int f0[4], f1[4], cq0[4], cq1[4], dq0[4], dq1[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                f0[i] = __builtin_amdgcn_readlane(dcraw, i * 4);
+                f1[i] = __builtin_amdgcn_readlane(dcraw, 16 + i * 4);
+            }
+            fwd_dc_chroma(f0, cq0, d.qpc);
+            inv_dc_chroma(cq0, dq0, d.qpc);
+            fwd_dc_chroma(f1, cq1, d.qpc);
+            inv_dc_chroma(cq1, dq1, d.qpc);
+            const int a = cb == 0 ? cq0[0] : (cb == 1 ? cq0[1] : (cb == 2 ? cq0[2] : cq0[3]));
+            const int b = cb == 0 ? cq1[0] : (cb == 1 ? cq1[1] : (cb == 2 ? cq1[2] : cq1[3]));
+            const int e = cb == 0 ? dq0[0] : (cb == 1 ? dq0[1] : (cb == 2 ? dq0[2] : dq0[3]));
+            const int g = cb == 0 ? dq1[0] : (cb == 1 ? dq1[1] : (cb == 2 ? dq1[2] : dq1[3]));
+            dcq = pl ? b : a;
+            dcdeq = pl ? g : e;
+        }
+        const uint32_t z = ((const uint32_t *)c_izz)[row];
+        int cnt = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const int k = (int)((z >> (8 * x)) & 15u);
+            if (k > 0) {  // (row 0, x 0) is the DC
+                if (act) lvs[FER_LV_CAC + cblk * 15 + k - 1] = (int16_t)c[x];
+                cnt += c[x] != 0;
+            }
+        }
+        cnt = quad_sum(cnt);
+        if (act && row == 0) {
+            tcs[16 + cblk] = (uint8_t)cnt;
+            lvs[FER_LV_CDC + cblk] = (int16_t)dcq;
+        }
+        nz_c = __ballot(act && cnt != 0);
+        dcm = __ballot(act && dcq != 0);
+        if (row == 0) c[0] = dcdeq;
+        inv_row(q, c, d.qpc, true, r);
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) o |= (uint32_t)clip255(pf[k] + r[k]) << (8 * k);
+        if (act) *(uint32_t *)dst = o;
     }
     __syncthreads();
-
-    int16_t *lv = d.levels + ((size_t)s * d.nmb + mb) * FER_LEVELS;
-    const bool isL = lane < 16, isC = lane >= 16 && lane < 24;
-    const int pl = (lane - 16) >> 2, cb = (lane - 16) & 3;  // chroma plane / block
-    int x0 = 0, y0 = 0, stride = W;
-    uint8_t *dst = Y;
-    const uint8_t *prd = &pL[0][0], *srd = &sL[0][0];
-    int pstride = 16;
-    if (isL) {
-        x0 = c_bx[lane];
-        y0 = c_by[lane];
-        dst = Y + (size_t)(yp + y0) * W + xp + x0;
-        prd = &pL[y0][x0];
-        srd = &sL[y0][x0];
-    } else if (isC) {
-        x0 = (cb & 1) * 4;
-        y0 = (cb >> 1) * 4;
-        stride = Wc;
-        dst = (pl ? C1 : C0) + (size_t)(yp / 2 + y0) * Wc + xp / 2 + x0;
-        prd = &pC[pl][y0][x0];
-        srd = &sC[pl][y0][x0];
-        pstride = 8;
-    }
-    int r[16], t[16], q[16], p[16];
-    int nz = 0, dcraw = 0;
-    const int qP = isL ? d.qp : d.qpc;
-    if (isL || isC) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            p[i] = prd[(i >> 2) * pstride + (i & 3)];
-            r[i] = (int)srd[(i >> 2) * pstride + (i & 3)] - p[i];
-        }
-        fwd4x4(r, t);
-        quant4x4(t, q, qP, isC);
-        dcraw = q[0];
-    }
-    // chroma DC: 2x2 Hadamard + quantiser on lanes 16 and 20, then back to the block lanes
-    int dcq = 0, dcdeq = 0;
     {
-        int base = 16 + (lane >= 20 ? 4 : 0);
-        int f[4], cq[4], dq[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) f[i] = __shfl(dcraw, base + i);
-        fwd_dc_chroma(f, cq, d.qpc);
-        inv_dc_chroma(cq, dq, d.qpc);
-        if (isC) {
-            dcq = cq[cb];
-            dcdeq = dq[cb];
-        }
+        uint32_t *g = (uint32_t *)(d.levels + ((size_t)s * d.nmb + mb) * FER_LEVELS);
+        for (int i = lane; i < FER_LEVELS / 2; i += 64) g[i] = ((const uint32_t *)lvs)[i];
+        if (lane < 6) ((uint32_t *)(d.tc + ((size_t)s * d.nmb + mb) * 24))[lane] = ((const uint32_t *)tcs)[lane];
     }
-    int cnt = 0;
-    if (isL) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            int v = q[c_zz[k]];
-            lv[lane * 16 + k] = (int16_t)v;
-            cnt += v != 0;
-        }
-        nz = cnt != 0;
-        inv4x4(q, r, qP, false);
-    } else if (isC) {
-        lv[FER_LV_CDC + pl * 4 + cb] = (int16_t)dcq;
-#pragma unroll
-        for (int k = 1; k < 16; k++) {
-            int v = q[c_zz[k]];
-            lv[FER_LV_CAC + (pl * 4 + cb) * 15 + k - 1] = (int16_t)v;
-            cnt += v != 0;
-        }
-        nz = cnt != 0;
-        q[0] = dcdeq;
-        inv4x4(q, r, qP, true);
-    }
-    if (isL || isC) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) dst[(size_t)(i >> 2) * stride + (i & 3)] = (uint8_t)clip255(p[i] + r[i]);
-        d.tc[((size_t)s * d.nmb + mb) * 24 + lane] = (uint8_t)cnt;
-    }
-    // coded block pattern
-    unsigned long long nzm = __ballot(nz != 0);
-    unsigned long long dcm = __ballot(isC && dcq != 0);
+    // coded block pattern (F/rbsp_encoding.cpp:21-105)
     if (lane == 0) {
         int l = 0;
         for (int i8 = 0; i8 < 4; i8++)
-            if ((nzm >> (i8 * 4)) & 0xf) l |= 1 << i8;
+            if ((nz_l >> (i8 * 16)) & 0xffffu) l |= 1 << i8;
         int ch = 0;
         if (dcm) ch |= 1;
-        if ((nzm >> 16) & 0xff) ch |= 2;
+        if (nz_c) ch |= 2;
         if (ch == 3) ch = 2;
         d.cbp[((size_t)s * d.nmb + mb) * 2] = (uint8_t)l;
         d.cbp[((size_t)s * d.nmb + mb) * 2 + 1] = (uint8_t)ch;

@@ -173,8 +173,9 @@ int ferhip_set_reference(ferhip_ctx *c, const void *src);
  * S Annex-B streams (4-byte start codes, as the reference reads them) of equal picture size are
  * decoded side by side: slice_data parsing runs one wavefront per picture over a window of pictures of
  * every stream at once, reconstruction one wavefront per macroblock, picture by picture.  out (host, may be NULL): [max_pictures][S][W*H*3/2], picture t of
- * stream s at (t*S + s)*W*H*3/2; pictures[s] = number decoded.  Syntax the GPU path does not
- * implement (sub-8x8 partitions, I_PCM, several reference indices) returns FERHIP_E_UNSUP. */
+ * stream s at (t*S + s)*W*H*3/2; pictures[s] = number decoded.  Sub-8x8 partitions, ref_idx_l0 and
+ * reference list modification are handled the way the reference handles them; syntax the
+ * GPU path does not implement (I_PCM, CABAC, High profiles, field coding, slice groups) returns FERHIP_E_UNSUP. */
 int ferhip_decode_streams(const uint8_t *const *streams, const size_t *lens, int nstreams, uint8_t *out,
                           int max_pictures, int *pictures, int *width, int *height);
 /* frees the window buffers ferhip_decode_streams keeps between calls (tens of GB for large batches); FERHIP_E_STATE
