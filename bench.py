@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=3, help="pictures of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--secondary", type=int, default=1, help="also time configs[1] (720p I-only) and configs[4] (decode)")
     ap.add_argument("--e2e", type=int, default=1, help="also time the PCIe-inclusive path (pinned host pictures in, host RBSP out)")
+    ap.add_argument("--probe-build", type=int, default=0, help="development only: a -DFER_PROBE library with FER_DBG set skips "
+                    "stages on purpose, so a wrong output hash is reported (\"ok\": false) instead of ending the run")
     ap.add_argument("--resolve-wgs", type=int, default=0, help="workgroups of the persistent motion-chain launch (0 = library default)")
     ap.add_argument("--resolve-group", type=int, default=0, help="streams per ticket group of the motion chain (0 = library default)")
     ap.add_argument("--dist-backend", default=os.environ.get("FER_BENCH_BACKEND", "nccl"),
@@ -337,7 +339,7 @@ def main():
         check["bytes"] = len(s0)
     if check["expected"] is not None:
         check["ok"] = check["rbsp_sha256"] == check["expected"]
-        if not check["ok"]:
+        if not check["ok"] and not args.probe_build:
             raise SystemExit(f"output hash mismatch: {check}")
     del host_rbsp, host_len
 

@@ -182,6 +182,15 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     d.S = S;
     d.qp = p->qp;
     d.qpc = k_qpc[p->qp];  // chroma_qp_index_offset == 0 (F/headers_and_parameter_sets.cpp:490)
+    for (int k = 0; k < 2; k++) {  // the three LevelScale / LevelQuantize values of each QP (F/scaleTransform.cpp:32-40)
+        static const int v[6][3] = {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}};
+        const int m = (k ? d.qpc : d.qp) % 6;
+        for (int c = 0; c < 3; c++) {
+            const int ls = 16 * v[m][c];
+            d.lsq[k][c] = (int16_t)ls;
+            d.lsq[k][3 + c] = (int16_t)((65536 + ls) / (2 * ls));
+        }
+    }
     d.window = p->window;
     d.maxdiff_set = p->maxdiff;
     d.basic = p->basic ? 1 : 0;

@@ -38,6 +38,7 @@
 struct FerDev {
     int W, H, Wc, Hc, mbw, mbh, nmb, S;
     int qp, qpc, window, maxdiff_set, basic;
+    int16_t lsq[2][6];  // [luma qp / chroma qpc][LevelScale of class (even,even), (odd,odd), mixed; then LevelQuantize likewise]
     int dbg;  // -DFER_PROBE builds only (env FER_DBG): bit mask that skips kernel stages for timing; the shipped
               // library compiles every test of it away (FER_DBGF)
     size_t ysz, csz;

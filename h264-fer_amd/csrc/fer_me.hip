@@ -1147,6 +1147,11 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
     int mvpx, mvpy;
     predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
     const int genx = mvpx >> 2, geny = mvpy >> 2;
+    if (FER_DBGF(d, 16)) {  // (probe: the chain without stage 1)
+        wkey = 0x7fffffff;
+        wxy = 0;
+        return false;
+    }
     WList L1;
     L1.m = INF_M;
     L1.xy = 0;
@@ -1345,47 +1350,13 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
         select_topk<FER_ST2_CAP / 64>(m2, 33, lane, sel_lds, L2, raw2, fin2);
     }
     const int cnt2 = __popcll(__ballot(lane < 33 && L2.m < 100000000));
+    if (FER_DBGF(d, 256)) L2.xy = pack_xy(lane & 7, lane >> 3);  // (probe: what the scattered SAD rows of stage 2 cost)
     int b2, b2xy;
     sad_keys<33>(L2, cnt2, lane, ip, W, H, sx, sy, P.sb, mvpx, mvpy, b2, b2xy);
     wave_best(b2, b2xy, k2, xy2);
     int key = 0x7fffffff;
     if (lane < P.n3) key = ((P.c3s + iabs(P.c3x - mvpx) + iabs(P.c3y - mvpy)) << 6) | lane;
     wave_best(key, pack_xy(P.c3x, P.c3y), k3, xy3);
-}
-
-// neighbour lookup of partition `part` of macroblock (mbx, mby): like nbr_locate, without divisions
-__device__ __forceinline__ void nbr_locate_xy(int mbw, int mbx, int mby, int xN, int yN, bool &valid, int &mbN, int &q)
-{
-    const int cur = mby * mbw + mbx;
-    int xW = xN, yW = yN;
-    mbN = cur;
-    q = 0;
-    valid = false;
-    if (xW > 15 && yW >= 0) return;
-    if (yW > 15) return;
-    valid = true;
-    if (!(xW >= 0 && xW < 16 && yW >= 0)) {
-        if (xW >= 0 && xW < 16) {  // above
-            mbN = cur - mbw;
-            valid = mby > 0;
-            yW += 16;
-        } else if (xW > 15) {      // above right
-            mbN = cur - mbw + 1;
-            valid = mby > 0 && mbx + 1 < mbw;
-            xW -= 16;
-            yW += 16;
-        } else if (yW < 0) {       // above left
-            mbN = cur - mbw - 1;
-            valid = mby > 0 && mbx > 0;
-            xW += 16;
-            yW += 16;
-        } else {                   // left
-            mbN = cur - 1;
-            valid = mbx > 0;
-            xW += 16;
-        }
-    }
-    q = ((yW >> 3) << 1) + (xW >> 3);
 }
 
 template <int WIN>

@@ -68,6 +68,41 @@ __device__ __forceinline__ void nbr_locate(int W, int cur, int xN, int yN, bool 
     q = ((yW >> 3) << 1) + (xW >> 3);
 }
 
+// neighbour lookup of partition `part` of macroblock (mbx, mby): like nbr_locate, without divisions
+__device__ __forceinline__ void nbr_locate_xy(int mbw, int mbx, int mby, int xN, int yN, bool &valid, int &mbN, int &q)
+{
+    const int cur = mby * mbw + mbx;
+    int xW = xN, yW = yN;
+    mbN = cur;
+    q = 0;
+    valid = false;
+    if (xW > 15 && yW >= 0) return;
+    if (yW > 15) return;
+    valid = true;
+    if (!(xW >= 0 && xW < 16 && yW >= 0)) {
+        if (xW >= 0 && xW < 16) {  // above
+            mbN = cur - mbw;
+            valid = mby > 0;
+            yW += 16;
+        } else if (xW > 15) {      // above right
+            mbN = cur - mbw + 1;
+            valid = mby > 0 && mbx + 1 < mbw;
+            xW -= 16;
+            yW += 16;
+        } else if (yW < 0) {       // above left
+            mbN = cur - mbw - 1;
+            valid = mby > 0 && mbx > 0;
+            xW += 16;
+            yW += 16;
+        } else {                   // left
+            mbN = cur - 1;
+            valid = mbx > 0;
+            xW += 16;
+        }
+    }
+    q = ((yW >> 3) << 1) + (xW >> 3);
+}
+
 // neighbour motion vector (all MBs of a P picture are inter in the encoder)
 __device__ void nbr_fetch(const MvCtx &c, int xN, int yN, bool &valid, int &mx, int &my, int &ref)
 {
@@ -212,5 +247,52 @@ __device__ void predict_luma_quadrant(const MvCtx &c, int part, const int sub[4]
     } else if (sub[0] == 2 && a_ok) {
         ox = ax;
         oy = ay;
+    }
+}
+
+// PredictMV_Luma (F/mode_pred.cpp:252-371) of partition `part` of an inter macroblock of type `type` in the encoder
+// (every macroblock of the picture is inter, reference index 0), with the neighbours' vectors already in registers:
+// lane j < 20 of `tbl` holds the packed vector of quadrant j & 3 of macroblock {cur, left, above, above right, above
+// left}[j >> 2].  All lanes must call this together (ds_bpermute); partition and type may differ per lane.
+__device__ __forceinline__ void predict_luma_tbl(int tbl, int mbw, int mbx, int mby, int type, int part, int &ox, int &oy)
+{
+    const int cur = mby * mbw + mbx;
+    const int pw = p_part_w(type), ph = p_part_h(type);
+    const int x = pw == 16 ? 0 : (part & 1) * 8, y = ph == 16 ? 0 : (pw == 16 ? part : (part >> 1)) * 8;
+    const int ppw = (type == FER_P_8x8 || type == FER_P_8x8ref0 || type == FER_P_8x16) ? 8 : 16;
+    auto fetch = [&](int xN, int yN, int &mx, int &my, int &ref) {
+        bool valid;
+        int mbN, q;
+        nbr_locate_xy(mbw, mbx, mby, xN, yN, valid, mbN, q);
+        const int which = mbN == cur ? 0 : (mbN == cur - 1 ? 1 : (mbN == cur - mbw ? 2 : (mbN == cur - mbw + 1 ? 3 : 4)));
+        const int w = __shfl(tbl, which * 4 + q);
+        mx = valid ? (int)(short)(w & 0xffff) : FER_MV_NA;
+        my = valid ? (w >> 16) : FER_MV_NA;
+        ref = valid ? 0 : -1;
+    };
+    int mx[3], my[3], ref[3], dx, dy, dr;
+    fetch(x - 1, y, mx[0], my[0], ref[0]);
+    fetch(x, y - 1, mx[1], my[1], ref[1]);
+    fetch(x + ppw, y - 1, mx[2], my[2], ref[2]);
+    fetch(x - 1, y - 1, dx, dy, dr);
+    if (ref[2] != 0) {  // C unavailable: D takes its place
+        mx[2] = dx;
+        my[2] = dy;
+        ref[2] = dr;
+    }
+    const bool useB = type == FER_P_16x8 && part == 0 && ref[1] == 0;
+    const bool useA = ((type == FER_P_16x8 && part == 1) || (type == FER_P_8x16 && part == 0)) && ref[0] == 0;
+    const bool useC = type == FER_P_8x16 && part == 1 && ref[2] == 0;
+    const int ax = mx[0], ay = my[0], bx = mx[1], by = my[1], cx = mx[2], cy = my[2];
+    predict_core(mx, my, ref, ox, oy);
+    if (useB) {
+        ox = bx;
+        oy = by;
+    } else if (useA) {
+        ox = ax;
+        oy = ay;
+    } else if (useC) {
+        ox = cx;
+        oy = cy;
     }
 }

@@ -7,6 +7,7 @@
 //   k_frame_sad |cur - ref| over the luma plane for the IDR decision   (F/ref_frames.cpp:210-219)
 #include <cstring>
 #include <string.h>
+#include <algorithm>
 #include "fer_internal.h"
 
 // ------------------------------------------------------------------ k_interp
@@ -646,22 +647,40 @@ void fer_launch_refprep(const FerDev &d, FerSortTmp &t, const int *types, hipStr
 }
 
 // ------------------------------------------------------------------ k_frame_sad
+// selectNALUnitType's whole-picture SAD (F/ref_frames.cpp:185-234): a pure stream of 2 bytes per luma sample, read as
+// 16-byte words, four of them in flight per lane
 __global__ __launch_bounds__(256) void k_frame_sad(FerDev d)
 {
-    int s = blockIdx.y;
-    const uint8_t *a = d.curY + (size_t)s * d.ysz, *b = d.refY + (size_t)s * d.ysz;
-    size_t n4 = d.ysz / 4;
-    unsigned acc = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        uint32_t va = ((const uint32_t *)a)[i], vb = ((const uint32_t *)b)[i];
-        acc = __builtin_amdgcn_sad_u8(va, vb, acc);
+    const int s = blockIdx.y;
+    const uint4 *a = (const uint4 *)(d.curY + (size_t)s * d.ysz), *b = (const uint4 *)(d.refY + (size_t)s * d.ysz);
+    const size_t n16 = d.ysz / 16, stride = (size_t)gridDim.x * blockDim.x;  // the luma plane is a multiple of 256 bytes
+    unsigned acc0 = 0, acc1 = 0;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + stride < n16; i += 2 * stride) {
+        const uint4 va = a[i], vb = b[i], wa = a[i + stride], wb = b[i + stride];
+        acc0 = __builtin_amdgcn_sad_u8(va.x, vb.x, acc0);
+        acc1 = __builtin_amdgcn_sad_u8(va.y, vb.y, acc1);
+        acc0 = __builtin_amdgcn_sad_u8(va.z, vb.z, acc0);
+        acc1 = __builtin_amdgcn_sad_u8(va.w, vb.w, acc1);
+        acc0 = __builtin_amdgcn_sad_u8(wa.x, wb.x, acc0);
+        acc1 = __builtin_amdgcn_sad_u8(wa.y, wb.y, acc1);
+        acc0 = __builtin_amdgcn_sad_u8(wa.z, wb.z, acc0);
+        acc1 = __builtin_amdgcn_sad_u8(wa.w, wb.w, acc1);
     }
-    int v = wave_sum((int)acc);
+    if (i < n16) {
+        const uint4 va = a[i], vb = b[i];
+        acc0 = __builtin_amdgcn_sad_u8(va.x, vb.x, acc0);
+        acc1 = __builtin_amdgcn_sad_u8(va.y, vb.y, acc1);
+        acc0 = __builtin_amdgcn_sad_u8(va.z, vb.z, acc0);
+        acc1 = __builtin_amdgcn_sad_u8(va.w, vb.w, acc1);
+    }
+    int v = wave_sum((int)(acc0 + acc1));
     if ((threadIdx.x & 63) == 0) atomicAdd(&d.sad[s], (unsigned long long)(unsigned)v);
 }
 
 void fer_launch_frame_sad(const FerDev &d, hipStream_t st)
 {
     hipMemsetAsync(d.sad, 0, sizeof(unsigned long long) * d.S, st);
-    hipLaunchKernelGGL(k_frame_sad, dim3(256, d.S), dim3(256), 0, st, d);
+    const int gx = (int)std::min<size_t>(64, std::max<size_t>(1, d.ysz / 16 / (256 * 8)));  // ~8 words of 16 bytes per lane
+    hipLaunchKernelGGL(k_frame_sad, dim3(gx, d.S), dim3(256), 0, st, d);
 }

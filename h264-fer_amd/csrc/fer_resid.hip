@@ -30,7 +30,7 @@ struct RowQ {  // per-lane constants of a row of a 4x4 block
     int lq[4], ls[4];    // LevelQuantize / LevelScale of (row, x)
 };
 
-__device__ __forceinline__ RowQ rowq_make(int row, int qP)
+__device__ __forceinline__ RowQ rowq_make(int row, const int16_t (&t)[6])  // t = FerDev::lsq[luma / chroma]
 {
     RowQ q;
     q.row = row;
@@ -39,9 +39,7 @@ __device__ __forceinline__ RowQ rowq_make(int row, int qP)
     q.k1 = r0 ? 256 : (r1 ? 208 : (r2 ? -256 : -416));
     q.k2 = r0 ? 256 : (r1 ? -208 : (r2 ? -256 : 416));
     q.k3 = (r0 || r2) ? 256 : (r1 ? -416 : -208);
-    const int m = qP % 6;
-    const int s_ee = level_scale(m, 0, 0), s_oo = level_scale(m, 1, 1), s_eo = level_scale(m, 0, 1);
-    const int q_ee = level_quant(m, 0, 0), q_oo = level_quant(m, 1, 1), q_eo = level_quant(m, 0, 1);
+    const int s_ee = t[0], s_oo = t[1], s_eo = t[2], q_ee = t[3], q_oo = t[4], q_eo = t[5];
     const bool odd = row & 1;
     q.ls[0] = q.ls[2] = odd ? s_eo : s_ee;
     q.ls[1] = q.ls[3] = odd ? s_oo : s_eo;
@@ -125,32 +123,62 @@ __device__ __forceinline__ void mc_chroma_row4(const uint8_t *__restrict__ R, in
     for (int k = 0; k < 4; k++) out[k] = (w00 * t[k] + w01 * t[k + 1] + w10 * u[k] + w11 * u[k + 1] + 32) >> 6;
 }
 
-__global__ __launch_bounds__(64) void k_p_resid(FerDev d)
+// A workgroup = four wavefronts = four macroblocks side by side (64-byte picture segments), and the workgroups are
+// dealt so that each XCD works on one contiguous band of the picture: a picture line is then fetched into ONE L2, once,
+// instead of by every XCD that happens to own one of its 16-sample pieces.  The wavefronts share nothing: their LDS
+// is private and ordered with wave-level fences, no s_barrier.
+#define RES_SYNC()                                             \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
+__global__ __launch_bounds__(256) void k_p_resid(FerDev d)
 {
-    __shared__ __align__(16) int16_t lvs[FER_LEVELS];
-    __shared__ __align__(4) uint8_t tcs[24];
-    const int lane = threadIdx.x;
-    const int s = blockIdx.y, mb = blockIdx.x;
-    if (d.hdr[s * 4 + 3] != 0) return;
-    int *mbt = d.mb_type + (size_t)s * d.nmb;
-    if (mbt[mb] == FER_P_SKIP) return;  // reconstructed by k_me_resolve
+    __shared__ __align__(16) int16_t lvs_[4][FER_LEVELS];
+    __shared__ __align__(4) uint8_t tcs_[4][24];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int16_t *lvs = lvs_[wv];
+    uint8_t *tcs = tcs_[wv];
+    const int s = blockIdx.y, mb = (int)xcd_swizzle(blockIdx.x, gridDim.x) * 4 + wv;
+    if (mb >= d.nmb) return;
     const int W = d.W, H = d.H, Wc = d.Wc, Hc = d.Hc;
+    int *mbt = d.mb_type + (size_t)s * d.nmb;
     uint8_t *Y = d.curY + (size_t)s * d.ysz;
     const uint8_t *RY = d.refY + (size_t)s * d.ysz;
     const short *mvs = d.mv + (size_t)s * d.nmb * 8;
-    const int xp = (mb % d.mbw) << 4, yp = (mb / d.mbw) << 4;
+    const int mbx = mb % d.mbw, mby = mb / d.mbw;
+    const int xp = mbx << 4, yp = mby << 4;
+    const int row = lane & 3;
+    // Everything that does not depend on the vectors is requested before the first test: the kernel is a chain of
+    // memory round trips (picture type -> macroblock type -> vectors -> reference samples -> stores), not a stream.
+    const int blk = lane >> 2;
+    const int lx = c_bx[blk], ly = c_by[blk] + row;
+    uint8_t *dstL = Y + (size_t)(yp + ly) * W + xp + lx;
+    const int l5 = lane & 31, cblk = l5 >> 2, pl = cblk >> 2, cb = cblk & 3;  // chroma: plane, block
+    const int cx0 = (cb & 1) * 4, cy0 = (cb >> 1) * 4 + row;
+    uint8_t *Cp = (pl ? d.curCr : d.curCb) + (size_t)s * d.csz;
+    const uint8_t *Rp = (pl ? d.refCr : d.refCb) + (size_t)s * d.csz;
+    uint8_t *dstC = Cp + (size_t)(yp / 2 + cy0) * Wc + xp / 2 + cx0;
+    const int ptype = (int)d.hdr[s * 4 + 3], mtype = mbt[mb];
+    const uint32_t svL = *(const uint32_t *)dstL, svC = *(const uint32_t *)dstC;
+    // the vectors of this macroblock and of its left / above / above-right / above-left neighbours, one per lane
+    int tbl;
+    {
+        const int which = min(lane >> 2, 4), q = lane & 3;
+        const int off = which == 0 ? 0 : (which == 1 ? -1 : (which == 2 ? -d.mbw : (which == 3 ? 1 - d.mbw : -1 - d.mbw)));
+        tbl = ((const int *)mvs)[(size_t)iclamp(mb + off, 0, d.nmb - 1) * 4 + q];
+    }
+    if (ptype != 0) return;
+    if (mtype == FER_P_SKIP) return;  // reconstructed by k_me_resolve
 
     // ---- partition merge and mvd under the final type (F/moestimation.cpp:529-560); every vector of the
     // picture is final here, so nothing below is read by another macroblock's decision
     int mvx[4], mvy[4];
-    {
-        const uint4 v = *(const uint4 *)(mvs + (size_t)mb * 8);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            mvx[i] = (int)(short)(w[i] & 0xffff);
-            mvy[i] = (int)w[i] >> 16;
-        }
+    for (int i = 0; i < 4; i++) {
+        const int w = __builtin_amdgcn_readlane(tbl, i);
+        mvx[i] = (int)(short)(w & 0xffff);
+        mvy[i] = w >> 16;
     }
     int type = FER_P_8x8ref0, stat = 4;
     if (mvx[0] == mvx[1] && mvx[0] == mvx[2] && mvx[0] == mvx[3] && mvy[0] == mvy[1] && mvy[0] == mvy[2] &&
@@ -164,24 +192,27 @@ __global__ __launch_bounds__(64) void k_p_resid(FerDev d)
         type = FER_P_8x16;
         stat = 3;
     }
-    auto mv_of = [&](int q, int &vx, int &vy) {  // vector of quadrant q (lane-dependent index: selects, no scratch)
-        vx = q == 0 ? mvx[0] : (q == 1 ? mvx[1] : (q == 2 ? mvx[2] : mvx[3]));
-        vy = q == 0 ? mvy[0] : (q == 1 ? mvy[1] : (q == 2 ? mvy[2] : mvy[3]));
+    auto mv_of = [&](int q, int &vx, int &vy) {  // vector of quadrant q (q differs per lane)
+        const int w = __shfl(tbl, q);
+        vx = (int)(short)(w & 0xffff);
+        vy = w >> 16;
     };
+    // the reference samples: luma row of four from the quarter-sample planes, chroma row of four (bilinear)
+    int pfL[4], pfC[4];
     {
-        MvCtx c;
-        c.mv = mvs;
-        c.mb_type = nullptr;
-        c.mbw = d.mbw;
-        c.cur = mb;
-        c.type = type;
-        c.coh = false;
+        int qx, qy;
+        mv_of((ly >> 3) * 2 + (lx >> 3), qx, qy);
+        mc_luma4(RY, ip_stream(d, s), W, H, xp, yp, lx, ly, qx, qy, pfL);
+        mv_of(cb, qx, qy);
+        mc_chroma_row4(Rp, Wc, Hc, xp / 2, yp / 2, cx0, cy0, qx, qy, pfC);
+    }
+    {
         const int np = type == FER_P_L0_16x16 ? 1 : (type == FER_P_8x8ref0 ? 4 : 2);
         const int i = lane & 3;  // lane i < 4 derives partition i: one pass of the predictor for all of them
         const int pi = i < np ? i : 0;
         const int q = (type == FER_P_16x8 && pi == 1) ? 2 : pi;  // quadrant that carries partition i's vector
         int px_, py_, qx, qy;
-        predict_luma(c, pi, px_, py_);
+        predict_luma_tbl(tbl, d.mbw, mbx, mby, type, pi, px_, py_);
         mv_of(q, qx, qy);
         if (lane < 4) {
             const int dvx = i < np ? qx - px_ : 0, dvy = i < np ? qy - py_ : 0;
@@ -193,32 +224,25 @@ __global__ __launch_bounds__(64) void k_p_resid(FerDev d)
         }
     }
     for (int i = lane; i < FER_LEVELS / 2; i += 64) ((uint32_t *)lvs)[i] = 0u;
-    __syncthreads();
-    const int row = lane & 3;
-    // ---- luma: prediction, source snapping (F/moestimation.cpp:561-584: a source sample within MAXDIFF of the
-    // prediction is replaced by it), residual, transform, levels, reconstruction
+    RES_SYNC();
+    // ---- luma: source snapping (F/moestimation.cpp:561-584: a source sample within MAXDIFF of the prediction is
+    // replaced by it), residual, transform, levels, reconstruction
     int MAXDIFF = d.maxdiff_set;
     unsigned long long nz_l;
     {
-        const int blk = lane >> 2;
-        const int lx = c_bx[blk], ly = c_by[blk] + row;
-        uint8_t *dst = Y + (size_t)(yp + ly) * W + xp + lx;
-        const uint32_t sv = *(const uint32_t *)dst;
         int srcv[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) srcv[k] = (sv >> (8 * k)) & 0xff;
+        for (int k = 0; k < 4; k++) srcv[k] = (svL >> (8 * k)) & 0xff;
         if (d.maxdiff_set == -1) {
             int mean = wave_sum(srcv[0] + srcv[1] + srcv[2] + srcv[3]) / 256;
             int dev = wave_sum(iabs(srcv[0] - mean) + iabs(srcv[1] - mean) + iabs(srcv[2] - mean) + iabs(srcv[3] - mean));
             MAXDIFF = dev / 256;
             if (MAXDIFF < 3) MAXDIFF = 3;
         }
-        int qx, qy, pf[4], r[4], c[4], dc0;
-        mv_of((ly >> 3) * 2 + (lx >> 3), qx, qy);
-        mc_luma4(RY, ip_stream(d, s), W, H, xp, yp, lx, ly, qx, qy, pf);
+        int r[4], c[4], dc0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) r[k] = iabs(srcv[k] - pf[k]) < MAXDIFF ? 0 : srcv[k] - pf[k];
-        const RowQ q = rowq_make(row, d.qp);
+        for (int k = 0; k < 4; k++) r[k] = iabs(srcv[k] - pfL[k]) < MAXDIFF ? 0 : srcv[k] - pfL[k];
+        const RowQ q = rowq_make(row, d.lsq[0]);
         fwd_row(q, r, d.qp, false, c, dc0);
         const uint32_t z = ((const uint32_t *)c_izz)[row];
         int cnt = 0;
@@ -233,28 +257,22 @@ __global__ __launch_bounds__(64) void k_p_resid(FerDev d)
         inv_row(q, c, d.qp, false, r);
         uint32_t o = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) o |= (uint32_t)clip255(pf[k] + r[k]) << (8 * k);
-        *(uint32_t *)dst = o;
+        for (int k = 0; k < 4; k++) o |= (uint32_t)clip255(pfL[k] + r[k]) << (8 * k);
+        *(uint32_t *)dstL = o;
     }
     // ---- chroma on lanes 0..31 (32..63 shadow them and store nothing): plane = lane >> 4, block = (lane >> 2) & 3
     unsigned long long nz_c, dcm;
     {
-        const int l5 = lane & 31, cblk = l5 >> 2, pl = cblk >> 2, cb = cblk & 3;
         const bool act = lane < 32;
-        const int x0 = (cb & 1) * 4, y0 = (cb >> 1) * 4 + row;
-        uint8_t *Cp = (pl ? d.curCr : d.curCb) + (size_t)s * d.csz;
-        const uint8_t *Rp = (pl ? d.refCr : d.refCb) + (size_t)s * d.csz;
-        uint8_t *dst = Cp + (size_t)(yp / 2 + y0) * Wc + xp / 2 + x0;
-        const uint32_t sv = *(const uint32_t *)dst;
-        int qx, qy, pf[4], r[4], c[4], dcraw;
-        mv_of(cb, qx, qy);
-        mc_chroma_row4(Rp, Wc, Hc, xp / 2, yp / 2, x0, y0, qx, qy, pf);
+        uint8_t *dst = dstC;
+        const int *pf = pfC;
+        int r[4], c[4], dcraw;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int sk = (sv >> (8 * k)) & 0xff;
+            const int sk = (svC >> (8 * k)) & 0xff;
             r[k] = iabs(sk - pf[k]) <= MAXDIFF ? 0 : sk - pf[k];
         }
-        const RowQ q = rowq_make(row, d.qpc);
+        const RowQ q = rowq_make(row, d.lsq[1]);
         fwd_row(q, r, d.qpc, true, c, dcraw);
         // chroma DC: 2x2 Hadamard + quantiser on the four DC values of each plane (row-0 lanes of its blocks)
         int dcq, dcdeq;
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(64) void k_p_resid(FerDev d)
         for (int k = 0; k < 4; k++) o |= (uint32_t)clip255(pf[k] + r[k]) << (8 * k);
         if (act) *(uint32_t *)dst = o;
     }
-    __syncthreads();
+    RES_SYNC();
     {
         uint32_t *g = (uint32_t *)(d.levels + ((size_t)s * d.nmb + mb) * FER_LEVELS);
         for (int i = lane; i < FER_LEVELS / 2; i += 64) g[i] = ((const uint32_t *)lvs)[i];
@@ -322,5 +340,5 @@ __global__ __launch_bounds__(64) void k_p_resid(FerDev d)
 
 void fer_launch_p_resid(const FerDev &d, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_p_resid, dim3(d.nmb, d.S), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(k_p_resid, dim3((d.nmb + 3) / 4, d.S), dim3(256), 0, st, d);
 }
