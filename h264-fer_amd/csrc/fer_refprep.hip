@@ -11,59 +11,79 @@
 #include "fer_internal.h"
 
 // ------------------------------------------------------------------ k_interp
-// block = 64x4 threads, each thread one pixel; LDS tile (64+5) x (4+5) of the clamped reference.
+// A workgroup = a 64 x 16 tile of the picture, a thread = four samples side by side of one row.  The tile and its
+// 2 / 3-sample apron sit in LDS shifted by two columns, so that the 12 bytes a thread needs of each of its six rows
+// (columns -2 .. +9 around its first sample) are three aligned dwords.  The nine vertical 6-tap values of columns
+// -2 .. +6 are shared by the four samples (the centre sample j filters them AFTER clipping, F/mocomp.cpp:71); every
+// plane gets one dword per thread.  Tiles are dealt so that one XCD owns a band of the picture: the apron rows a tile
+// shares with the tiles above and below are then fetched into one L2.
 #define IT_W 64
-#define IT_H 4
+#define IT_H 16
+#define IT_PITCH 72  // bytes of a tile row: 64 + 5 apron columns, rounded up to dwords
 __global__ __launch_bounds__(256) void k_interp(FerDev d)
 {
-    __shared__ uint8_t tile[IT_H + 5][IT_W + 8];
-    int s = blockIdx.z;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[IT_H + 5][IT_PITCH];
+    const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;  // only P pictures search
+    const int W = d.W, H = d.H;
     const uint8_t *R = d.refY + (size_t)s * d.ysz;
     uint8_t *P = d.interp + (size_t)s * 16 * d.iplane + d.ioff;
-    int x0 = blockIdx.x * IT_W, y0 = blockIdx.y * IT_H;
-    int tid = threadIdx.y * IT_W + threadIdx.x;
-    for (int i = tid; i < (IT_H + 5) * (IT_W + 5); i += 256) {
-        int ty = i / (IT_W + 5), tx = i % (IT_W + 5);
-        int sx = iclamp(x0 + tx - 2, 0, d.W - 1), sy = iclamp(y0 + ty - 2, 0, d.H - 1);
-        tile[ty][tx] = R[sy * d.W + sx];
+    const int tw = (W + IT_W - 1) / IT_W;
+    const int t = (int)xcd_swizzle(blockIdx.x, gridDim.x);
+    const int x0 = (t % tw) * IT_W, y0 = (t / tw) * IT_H;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (IT_H + 5) * (IT_PITCH / 4); i += 256) {
+        const int r = i / (IT_PITCH / 4), c4 = (i % (IT_PITCH / 4)) * 4;
+        const int y = iclamp(y0 + r - 2, 0, H - 1), xs = x0 + c4 - 2;  // tile byte c4 = picture column xs
+        uint32_t v;
+        if (xs >= 0 && xs + 3 < W) {
+            v = load_u8x4(R + (size_t)y * W + xs);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= (uint32_t)R[(size_t)y * W + iclamp(xs + k, 0, W - 1)] << (8 * k);
+        }
+        *(uint32_t *)&tile[r][c4] = v;
     }
     __syncthreads();
-    int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
-    if (x >= d.W || y >= d.H) return;
-    int lx = threadIdx.x + 2, ly = threadIdx.y + 2;
-#define T(dx, dy) ((int)tile[ly + (dy)][lx + (dx)])
-    int G = T(0, 0);
-    int b = tap6(T(-2, 0), T(-1, 0), G, T(1, 0), T(2, 0), T(3, 0));
-    int h = tap6(T(0, -2), T(0, -1), G, T(0, 1), T(0, 2), T(0, 3));
-    int m = tap6(T(1, -2), T(1, -1), T(1, 0), T(1, 1), T(1, 2), T(1, 3));
-    int sS = tap6(T(-2, 1), T(-1, 1), T(0, 1), T(1, 1), T(2, 1), T(3, 1));
-    int cc = tap6(T(-2, -2), T(-2, -1), T(-2, 0), T(-2, 1), T(-2, 2), T(-2, 3));
-    int dd = tap6(T(-1, -2), T(-1, -1), T(-1, 0), T(-1, 1), T(-1, 2), T(-1, 3));
-    int ee = tap6(T(2, -2), T(2, -1), T(2, 0), T(2, 1), T(2, 2), T(2, 3));
-    int ff = tap6(T(3, -2), T(3, -1), T(3, 0), T(3, 1), T(3, 2), T(3, 3));
-    int j = tap6(cc, dd, h, m, ee, ff);
-    int v[16];
-    v[0] = G;
-    v[1] = FER_MID(G, b);
-    v[2] = b;
-    v[3] = FER_MID(b, T(1, 0));
-    v[4] = FER_MID(G, h);
-    v[5] = FER_MID(b, h);
-    v[6] = FER_MID(b, j);
-    v[7] = FER_MID(b, m);
-    v[8] = h;
-    v[9] = FER_MID(h, j);
-    v[10] = j;
-    v[11] = FER_MID(j, m);
-    v[12] = FER_MID(h, T(0, 1));
-    v[13] = FER_MID(h, sS);
-    v[14] = FER_MID(j, sS);
-    v[15] = FER_MID(sS, m);
-#undef T
-    size_t o = (size_t)y * d.ipitch + x;
+    const int g = tid & 15, ty = tid >> 4;
+    const int x = x0 + g * 4, y = y0 + ty;
+    if (x >= W || y >= H) return;
+    // rows y-2 .. y+3, columns x-2 .. x+6 (tv[r][k] = sample (x - 2 + k, y - 2 + r))
+    int tv[6][9];
 #pragma unroll
-    for (int f = 0; f < 16; f++) P[(size_t)f * d.iplane + o] = (uint8_t)v[f];
+    for (int r = 0; r < 6; r++) {
+        const uint32_t *w = (const uint32_t *)&tile[ty + r][g * 4];
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            tv[r][k] = (w0 >> (8 * k)) & 0xff;
+            tv[r][4 + k] = (w1 >> (8 * k)) & 0xff;
+        }
+        tv[r][8] = w2 & 0xff;
+    }
+    int V[9];  // vertical half-sample values of the nine columns
+#pragma unroll
+    for (int k = 0; k < 9; k++) V[k] = tap6(tv[0][k], tv[1][k], tv[2][k], tv[3][k], tv[4][k], tv[5][k]);
+    uint32_t o[16];
+#pragma unroll
+    for (int f = 0; f < 16; f++) o[f] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int G = tv[2][k + 2];
+        const int b = tap6(tv[2][k], tv[2][k + 1], G, tv[2][k + 3], tv[2][k + 4], tv[2][k + 5]);
+        const int sS = tap6(tv[3][k], tv[3][k + 1], tv[3][k + 2], tv[3][k + 3], tv[3][k + 4], tv[3][k + 5]);
+        const int h = V[k + 2], m = V[k + 3];
+        const int j = tap6(V[k], V[k + 1], h, m, V[k + 4], V[k + 5]);
+        const int v[16] = {G,          FER_MID(G, b), b,  FER_MID(b, tv[2][k + 3]), FER_MID(G, h),           FER_MID(b, h),
+                           FER_MID(b, j), FER_MID(b, m), h,  FER_MID(h, j),            j,                       FER_MID(j, m),
+                           FER_MID(h, tv[3][k + 2]), FER_MID(h, sS), FER_MID(j, sS),   FER_MID(sS, m)};
+#pragma unroll
+        for (int f = 0; f < 16; f++) o[f] |= (uint32_t)v[f] << (8 * k);
+    }
+    const size_t off = (size_t)y * d.ipitch + x;
+#pragma unroll
+    for (int f = 0; f < 16; f++) *(uint32_t *)(P + (size_t)f * d.iplane + off) = o[f];
 }
 
 // right and bottom margins of the 16 planes: pixel (x, y) beyond the picture = the plane's (min(x, W-1), min(y, H-1))
@@ -590,8 +610,8 @@ size_t fer_sort_tmp_bytes(int n, int S)
 // host side: prepare the reference structures of all P-picture streams (profiled steps)
 void fer_launch_interp(const FerDev &d, hipStream_t st)
 {
-    dim3 gi((d.W + IT_W - 1) / IT_W, (d.H + IT_H - 1) / IT_H, d.S);
-    hipLaunchKernelGGL(k_interp, gi, dim3(IT_W, IT_H), 0, st, d);
+    dim3 gi(((d.W + IT_W - 1) / IT_W) * ((d.H + IT_H - 1) / IT_H), d.S);
+    hipLaunchKernelGGL(k_interp, gi, dim3(256), 0, st, d);
     hipLaunchKernelGGL(k_interp_pad, dim3(8, 16, d.S), dim3(256), 0, st, d);
 }
 
