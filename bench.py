@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--content", choices=["textured", "letterbox", "flat-half", "still"], default="textured",
                     help="synthetic content variant: letterbox = 128 black-ish rows top and bottom, flat-half = left half one "
                          "value (large flat areas), still = no motion and no noise (P_Skip heavy)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("FER_BENCH_STREAMS", "128")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("FER_BENCH_STREAMS", "256")))
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("FER_BENCH_CONTEXTS", "2")),
                     help="encoder contexts per GPU, each on its own HIP stream and host thread (streams are split evenly)")
     ap.add_argument("--cpu-frames", type=int, default=3, help="pictures of the CPU-baseline sample (0 = skip)")
@@ -216,7 +216,7 @@ def main():
     for e in encs:
         # the persistent motion-chain launch of a context takes its share of the GPU's workgroup slots: with two
         # contexts each leaves room for the other's streaming kernels
-        e.tune(1, args.resolve_wgs or max(768, 3072 // NC))
+        e.tune(1, args.resolve_wgs or max(768, min(3072, 24 * e.S)))  # measured: 64 streams -> 1536, 128 and more -> 3072
         if args.resolve_group:
             e.tune(2, args.resolve_group)
 
