@@ -477,13 +477,13 @@ def run_secondary(pkg, torch, dev):
     e.close()
     del fr
     # ---- 1080p decode of the encoder's own IPPP output (host Annex-B in, pictures left in HBM)
-    W, H, S, T = 1920, 1072, 16, 8
+    W, H, S, T = 1920, 1072, 16, 30  # one full GOP: the I picture's 252 anti-diagonal launches are amortised as in the encoder's workload
     fr = gen_frames_torch(W, H, T, S, dev, seed=1234, noise=2).cpu().numpy()
     e = pkg.FerHip(W, H, S, qp=12, window=32, maxdiff=3, intra_every=30)
     streams, _ = e.encode_streams(fr)
     nmb = e.nmb
     e.close()
-    reps = 4
+    reps = 8
     batch = streams * reps
     pkg.decode_streams(batch, T, want_pictures=False)   # first call allocates the window arena
     t0 = time.perf_counter()

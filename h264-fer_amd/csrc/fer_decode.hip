@@ -932,22 +932,42 @@ __global__ __launch_bounds__(64) void k_dec_intra(FerDev d, int diag)
                         Y + (size_t)(yp + y0) * W + xp + x0, W);
         }
     } else {
+        // Intra4x4: the blocks reconstruct one after the other (each predicts from the ones before it); four lanes per
+        // block, lane r < 4 = row r (inv_row: the vertical half of the inverse transform crosses the quad with DPP),
+        // the levels of the macroblock staged in LDS by one coalesced read
+        ((uint32_t *)&L.lv4[0][0])[lane] = ((const uint32_t *)lv)[lane];
+        ((uint32_t *)&L.lv4[0][0])[64 + lane] = ((const uint32_t *)lv)[64 + lane];
         __syncthreads();
-        if (lane == 0) {
-            for (int blk = 0; blk < 16; blk++) {
-                int p[13], o[16], c[16], r[16];
-                fetch4(L, blk, lastcol, p);
-                pred4x4(d.i4mode[mbi * 16 + blk], p, o);
-                for (int i = 0; i < 16; i++) c[i] = 0;
-                for (int kk = 0; kk < 16; kk++) c[c_zz[kk]] = lv[blk * 16 + kk];
-                inv4x4(c, r, QPy, false);
-                int x0 = c_bx[blk], y0 = c_by[blk];
-                for (int i = 0; i < 16; i++) {
-                    int v = clip255(o[i] + r[i]);
-                    L.fr[1 + y0 + (i >> 2)][1 + x0 + (i & 3)] = (int16_t)v;
-                    Y[(size_t)(yp + y0 + (i >> 2)) * W + xp + x0 + (i & 3)] = (uint8_t)v;
+        const int row = lane & 3;
+        RowQ rq;
+        rq.row = row;
+        {
+            const int m = QPy % 6;
+            const int s_ee = level_scale(m, 0, 0), s_oo = level_scale(m, 1, 1), s_eo = level_scale(m, 0, 1);
+            rq.ls[0] = rq.ls[2] = (row & 1) ? s_eo : s_ee;
+            rq.ls[1] = rq.ls[3] = (row & 1) ? s_oo : s_eo;
+        }
+        const uint32_t zrow = ((const uint32_t *)c_izz)[row];
+        for (int blk = 0; blk < 16; blk++) {
+            int p[13], o[16], c[4], r[4];
+            fetch4(L, blk, lastcol, p);
+            pred4x4(d.i4mode[mbi * 16 + blk], p, o);
+#pragma unroll
+            for (int k = 0; k < 4; k++) c[k] = L.lv4[blk][(zrow >> (8 * k)) & 15u];
+            inv_row(rq, c, QPy, false, r);
+            const int x0 = c_bx[blk], y0 = c_by[blk];
+            if (lane < 4) {
+                uint32_t pk = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int po = row == 0 ? o[k] : (row == 1 ? o[4 + k] : (row == 2 ? o[8 + k] : o[12 + k]));
+                    const int v = clip255(po + r[k]);
+                    L.fr[1 + y0 + row][1 + x0 + k] = (int16_t)v;
+                    pk |= (uint32_t)v << (8 * k);
                 }
+                *(uint32_t *)(Y + (size_t)(yp + y0 + row) * W + xp + x0) = pk;
             }
+            __syncthreads();
         }
     }
     __syncthreads();

@@ -511,6 +511,95 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned n)
 #define DPP_WAVE_SHR1 0x138  // lane i <- lane i-1 over the whole wavefront
 
 // sum over each row of 16 lanes, result in every lane of the row
+// ---------------------------------------------------------------- 4x4 transforms, four lanes per block
+// lane = block * 4 + row holds one ROW of its block; the vertical half of every transform crosses the four lanes of a
+// quad with DPP quad_perm broadcasts, the horizontal half stays in the lane (k_p_resid, the Intra4x4 chain of k_intra_mb)
+// scan position of raster sample (row, x): the inverse of c_zz, one dword of four positions per row
+static __constant__ __align__(4) uint8_t c_izz[16] = {0, 1, 5, 6, 2, 4, 7, 12, 3, 8, 11, 13, 9, 10, 14, 15};
+
+#define QB0 0x00  // quad_perm broadcasts of lane 0..3 of the quad
+#define QB1 0x55
+#define QB2 0xAA
+#define QB3 0xFF
+
+struct RowQ {  // per-lane constants of a row of a 4x4 block
+    int row;
+    int k0, k1, k2, k3;  // vertical forward coefficients of this row (F/quantizationTransform.cpp:41-100)
+    int lq[4], ls[4];    // LevelQuantize / LevelScale of (row, x)
+};
+
+__device__ __forceinline__ RowQ rowq_make(int row, const int16_t (&t)[6])  // t = FerDev::lsq[luma / chroma]
+{
+    RowQ q;
+    q.row = row;
+    const bool r0 = row == 0, r1 = row == 1, r2 = row == 2;
+    q.k0 = (r0 || r2) ? 256 : (r1 ? 416 : 208);
+    q.k1 = r0 ? 256 : (r1 ? 208 : (r2 ? -256 : -416));
+    q.k2 = r0 ? 256 : (r1 ? -208 : (r2 ? -256 : 416));
+    q.k3 = (r0 || r2) ? 256 : (r1 ? -416 : -208);
+    const int s_ee = t[0], s_oo = t[1], s_eo = t[2], q_ee = t[3], q_oo = t[4], q_eo = t[5];
+    const bool odd = row & 1;
+    q.ls[0] = q.ls[2] = odd ? s_eo : s_ee;
+    q.ls[1] = q.ls[3] = odd ? s_oo : s_eo;
+    q.lq[0] = q.lq[2] = odd ? q_eo : q_ee;
+    q.lq[1] = q.lq[3] = odd ? q_oo : q_eo;
+    return q;
+}
+
+// a1 + a2 on the row r[0..3] (residual) of this lane: forward core (vertical across the quad, then horizontal) and
+// quantiser; c = levels of (row, x); returns the unquantised DC in dc0 (meaningful in row 0)
+__device__ __forceinline__ void fwd_row(const RowQ &q, const int r[4], int qP, bool keepDC, int c[4], int &dc0)
+{
+    int f[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const int h = r[x] == 0 ? 0 : r[x] * 64 - 32;
+        const int a = FER_DPP(h, QB0), b = FER_DPP(h, QB1), cc = FER_DPP(h, QB2), e = FER_DPP(h, QB3);
+        f[x] = (q.k0 * a + q.k1 * b + q.k2 * cc + q.k3 * e + 512) >> 10;
+    }
+    int t[4];
+    t[0] = (256 * (f[0] + f[1] + f[2] + f[3]) + 512) >> 10;
+    t[1] = (416 * f[0] + 208 * f[1] - 208 * f[2] - 416 * f[3] + 512) >> 10;
+    t[2] = (256 * (f[0] - f[1] - f[2] + f[3]) + 512) >> 10;
+    t[3] = (208 * f[0] - 416 * f[1] + 416 * f[2] - 208 * f[3] + 512) >> 10;
+    const int q6 = qP / 6;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const int v = qP < 24 ? ((t[x] * (1 << (4 - q6))) - (1 << (3 - q6))) * q.lq[x] : (t[x] >> (q6 - 4)) * q.lq[x];
+        c[x] = (v + 16384) >> 15;
+    }
+    dc0 = t[0];
+    if (keepDC && q.row == 0) c[0] = t[0];
+}
+
+// a6 + a7: dequantiser, inverse core (horizontal in the lane, then vertical across the quad) -> residual row
+__device__ __forceinline__ void inv_row(const RowQ &q, const int c[4], int qP, bool keepDC, int r[4])
+{
+    const int q6 = qP / 6;
+    int dq[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+        dq[x] = qP >= 24 ? (c[x] * q.ls[x]) * (1 << (q6 - 4)) : (c[x] * q.ls[x] + (1 << (3 - q6))) >> (4 - q6);
+    if (keepDC && q.row == 0) dq[0] = c[0];
+    const int e0 = dq[0] + dq[2], e1 = dq[0] - dq[2], e2 = (dq[1] >> 1) - dq[3], e3 = dq[1] + (dq[3] >> 1);
+    const int E[4] = {e0 + e3, e1 + e2, e1 - e2, e0 - e3};
+    const bool outer = q.row == 0 || q.row == 3, plus = q.row < 2;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const int a = FER_DPP(E[x], QB0), b = FER_DPP(E[x], QB1), cc = FER_DPP(E[x], QB2), e = FER_DPP(E[x], QB3);
+        const int g0 = a + cc, g1 = a - cc, g2 = (b >> 1) - e, g3 = b + (e >> 1);
+        const int u = outer ? g0 : g1, w = outer ? g3 : g2;
+        r[x] = ((plus ? u + w : u - w) + 32) >> 6;
+    }
+}
+
+__device__ __forceinline__ int quad_sum(int v)
+{
+    v += FER_DPP(v, DPP_QUAD_XOR1);
+    v += FER_DPP(v, DPP_QUAD_XOR2);
+    return v;
+}
+
 __device__ __forceinline__ int row16_sum(int v)
 {
     v += FER_DPP(v, DPP_QUAD_XOR1);

@@ -269,7 +269,13 @@ __global__ __launch_bounds__(64) void k_intra_mb(FerDev d, int diag)
     // ---- phase 4: Intra4x4 reconstruction chain (F/intra.cpp:1062-1086), serial over the 16 blocks
     const uint8_t *nmode = d.i4mode + (size_t)s * d.nmb * 16;
     const int *mbt = d.mb_type + (size_t)s * d.nmb;
-    if (lane == 0) {
+    // Four lanes per block: lane r < 4 owns row r of the block being reconstructed (fwd_row / inv_row, the vertical
+    // transform halves cross the quad with DPP); the other lanes shadow them and write nothing.  The chain itself is
+    // serial by construction: a block predicts from the reconstruction of the blocks before it.
+    {
+        const int row = lane & 3;
+        const RowQ rq = rowq_make(row, d.lsq[0]);
+        const uint32_t zrow = ((const uint32_t *)c_izz)[row];
         for (int blk = 0; blk < 16; blk++) {
             // setIntra4x4PredMode (F/intra.cpp:878-942)
             bool edgeA = blk == 0 || blk == 2 || blk == 8 || blk == 10;
@@ -288,24 +294,35 @@ __global__ __launch_bounds__(64) void k_intra_mb(FerDev d, int diag)
                 } else
                     mB = L.mode4[c_nbB[blk]];
             }
-            int pm = mA <= mB ? mA : mB, mode = L.mode4[blk];
-            L.flag4[blk] = (uint8_t)(mode == pm ? 8 : (mode < pm ? mode : mode - 1));
-            int p[13], o[16], r[16], t[16], qv[16];
+            const int pm = mA <= mB ? mA : mB, mode = L.mode4[blk];
+            int p[13], o[16], r[4], c[4], dc0;
             fetch4(L, blk, lastcol, p);
             pred4x4(mode, p, o);
-            int x0 = c_bx[blk], y0 = c_by[blk];
-            for (int i = 0; i < 16; i++) r[i] = L.fr[1 + y0 + (i >> 2)][1 + x0 + (i & 3)] - o[i];
-            fwd4x4(r, t);
-            quant4x4(t, qv, QPy, false);
-            int cnt = 0;
-            for (int k = 0; k < 16; k++) {
-                int v = qv[c_zz[k]];
-                L.lv4[blk][k] = (int16_t)v;
-                cnt += v != 0;
+            const int x0 = c_bx[blk], y0 = c_by[blk];
+            int po[4];  // the lane's row of the prediction
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                po[k] = row == 0 ? o[k] : (row == 1 ? o[4 + k] : (row == 2 ? o[8 + k] : o[12 + k]));
+                r[k] = L.fr[1 + y0 + row][1 + x0 + k] - po[k];
             }
-            L.tc4[blk] = (uint8_t)cnt;
-            inv4x4(qv, r, QPy, false);
-            for (int i = 0; i < 16; i++) L.fr[1 + y0 + (i >> 2)][1 + x0 + (i & 3)] = (int16_t)clip255(o[i] + r[i]);
+            fwd_row(rq, r, QPy, false, c, dc0);
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (lane < 4) L.lv4[blk][(zrow >> (8 * k)) & 15u] = (int16_t)c[k];
+                cnt += c[k] != 0;
+            }
+            cnt = quad_sum(cnt);
+            inv_row(rq, c, QPy, false, r);
+            if (lane < 4) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) L.fr[1 + y0 + row][1 + x0 + k] = (int16_t)clip255(po[k] + r[k]);
+            }
+            if (lane == 0) {
+                L.flag4[blk] = (uint8_t)(mode == pm ? 8 : (mode < pm ? mode : mode - 1));
+                L.tc4[blk] = (uint8_t)cnt;
+            }
+            __syncthreads();  // (one wavefront: orders the LDS traffic of this block before the next one's)
         }
     }
     __syncthreads();
@@ -341,16 +358,23 @@ __global__ __launch_bounds__(64) void k_intra_mb(FerDev d, int diag)
         int x0 = c_bx[lane], y0 = c_by[lane];
         uint8_t *dst = Y + (size_t)(yp + y0) * W + xp + x0;
         if (use4) {
-            for (int i = 0; i < 16; i++) dst[(size_t)(i >> 2) * W + (i & 3)] = (uint8_t)L.fr[1 + y0 + (i >> 2)][1 + x0 + (i & 3)];
+            for (int ry = 0; ry < 4; ry++) {  // one dword per block row
+                uint32_t o = 0;
+                for (int k = 0; k < 4; k++) o |= (uint32_t)(uint8_t)L.fr[1 + y0 + ry][1 + x0 + k] << (8 * k);
+                *(uint32_t *)(dst + (size_t)ry * W) = o;
+            }
             for (int k = 0; k < 16; k++) lv[lane * 16 + k] = L.lv4[lane][k];
             d.tc[mbi * 24 + lane] = L.tc4[lane];
         } else {
             int r[16];
             q16v[0] = L.dcdeq[(y0 >> 2) * 4 + (x0 >> 2)];
             inv4x4(q16v, r, QPy, true);
-            for (int i = 0; i < 16; i++)
-                dst[(size_t)(i >> 2) * W + (i & 3)] =
-                    (uint8_t)clip255(pred16_px(L, q16, mode16, x0 + (i & 3), y0 + (i >> 2)) + r[i]);
+            for (int ry = 0; ry < 4; ry++) {
+                uint32_t o = 0;
+                for (int k = 0; k < 4; k++)
+                    o |= (uint32_t)clip255(pred16_px(L, q16, mode16, x0 + k, y0 + ry) + r[ry * 4 + k]) << (8 * k);
+                *(uint32_t *)(dst + (size_t)ry * W) = o;
+            }
             for (int k = 0; k < 16; k++) lv[lane * 16 + k] = L.lv16[lane][k];
             lv[FER_LV_DC16 + lane] = L.dc16[lane];
             d.tc[mbi * 24 + lane] = L.tc16[lane];
@@ -360,7 +384,9 @@ __global__ __launch_bounds__(64) void k_intra_mb(FerDev d, int diag)
     } else if (isC) {
         int x0 = (cb & 1) * 4, y0 = (cb >> 1) * 4;
         uint8_t *dst = Cp[pl] + (size_t)(yp / 2 + y0) * Wc + xp / 2 + x0;
-        for (int i = 0; i < 16; i++) dst[(size_t)(i >> 2) * Wc + (i & 3)] = (uint8_t)crec[i];
+        for (int ry = 0; ry < 4; ry++)
+            *(uint32_t *)(dst + (size_t)ry * Wc) = (uint32_t)crec[ry * 4] | ((uint32_t)crec[ry * 4 + 1] << 8) |
+                                                  ((uint32_t)crec[ry * 4 + 2] << 16) | ((uint32_t)crec[ry * 4 + 3] << 24);
         lv[FER_LV_CDC + pl * 4 + cb] = L.cdc[pl][cb];
         for (int k = 0; k < 15; k++) lv[FER_LV_CAC + (pl * 4 + cb) * 15 + k] = L.cac[pl][cb][k];
         d.tc[mbi * 24 + lane] = L.tcc[pl][cb];
