@@ -216,7 +216,7 @@ def main():
     for e in encs:
         # the persistent motion-chain launch of a context takes its share of the GPU's workgroup slots: with two
         # contexts each leaves room for the other's streaming kernels
-        e.tune(1, args.resolve_wgs or max(768, min(3072, 24 * e.S)))  # measured: 64 streams -> 1536, 128 and more -> 3072
+        e.tune(1, args.resolve_wgs or (3072 if NC == 1 else max(768, min(3072, 24 * e.S))))  # two contexts share the workgroup slots; measured: 64 streams -> 1536, 128 and more -> 3072
         if args.resolve_group:
             e.tune(2, args.resolve_group)
 

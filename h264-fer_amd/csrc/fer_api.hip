@@ -1064,6 +1064,7 @@ extern "C" size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t
     case FERHIP_BUF_I4MODE: src = d.i4mode; n = nm * 16; break;
     case FERHIP_BUF_TIMING: src = d.timing; n = 64 * 8; break;
     case FERHIP_BUF_ST2N: src = d.st2n; n = nm * 16; break;
+    case FERHIP_BUF_ST2: src = d.st2; n = nm * 4 * FER_ST2_CAP * 8; break;
     case FERHIP_BUF_CUR:
     case FERHIP_BUF_REF: {
         n = d.ysz * 3 / 2 * d.S;

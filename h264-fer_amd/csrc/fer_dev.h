@@ -30,6 +30,7 @@
 #define FER_IP_B 12
 #define FER_BRANGE_MIN 1024  // buckets with more positions than this get feature ranges (FerDev.brange)
 #define FER_ST2_CAP 384  // stage-2 candidates kept per 8x8 partition
+#define FER_BIG_SLICE 1024  // records of one bucket inside a partition's column range beyond which k_me_walk bounds instead of reading
 #define FER_LEVELS 400   // int16 per MB: luma 16x16, dc16 16, cdc 2x4, cac 2x4x15
 #define FER_LV_DC16 256
 #define FER_LV_CDC 272
@@ -221,10 +222,14 @@ __device__ __forceinline__ int level_scale(int m, int i, int j)
     int cls = ((i | j) & 1) == 0 ? 0 : ((i & j & 1) ? 1 : 2);
     return 16 * v[m][cls];
 }
+// (derived at compile time: an integer division per coefficient in the kernels otherwise)
+#define FER_LQ(v) ((65536 + 16 * (v)) / (2 * 16 * (v)))
 __device__ __forceinline__ int level_quant(int m, int i, int j)
 {
-    int ls = level_scale(m, i, j);
-    return (65536 + ls) / (2 * ls);
+    const int q[6][3] = {{FER_LQ(10), FER_LQ(16), FER_LQ(13)}, {FER_LQ(11), FER_LQ(18), FER_LQ(14)}, {FER_LQ(13), FER_LQ(20), FER_LQ(16)},
+                         {FER_LQ(14), FER_LQ(23), FER_LQ(18)}, {FER_LQ(16), FER_LQ(25), FER_LQ(20)}, {FER_LQ(18), FER_LQ(29), FER_LQ(23)}};
+    int cls = ((i | j) & 1) == 0 ? 0 : ((i & j & 1) ? 1 : 2);
+    return q[m][cls];
 }
 
 // ---------------------------------------------------------------- 4x4 transforms (one block per lane)

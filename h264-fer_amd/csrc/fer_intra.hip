@@ -224,24 +224,49 @@ __global__ __launch_bounds__(64) void k_intra_mb(FerDev d, int diag)
         int hb = ue_len((unsigned)t16) + ue_len((unsigned)chroma_mode) + 1;
         BitW w;
         bw_init<false>(w, nullptr, 0, 0);
-        if (lane == 0)
-            cavlc_block<false>(w, L.dc16, 16, nC_local(d, s, mb, true, 0, 0, L.tc16, L.tcc, cbpL16, cbpC, stale_skip));
-        if (lane >= 1 && lane <= 16 && cbpL16)
-            cavlc_block<false>(w, L.lv16[lane - 1], 15,
-                               nC_local(d, s, mb, true, lane - 1, 0, L.tc16, L.tcc, cbpL16, cbpC, stale_skip));
-        if ((lane == 17 || lane == 18) && (cbpC & 3)) cavlc_block<false>(w, L.cdc[lane - 17], 4, -1);
-        if (lane >= 19 && lane < 27 && (cbpC & 2)) {
-            int k = (lane - 19) >> 2, b = (lane - 19) & 3;
-            cavlc_block<false>(w, L.cac[k][b], 15, nC_local(d, s, mb, false, b, k, L.tc16, L.tcc, cbpL16, cbpC, stale_skip));
+        // one residual block per lane (0: the DC block, 1..16: luma AC, 17..18: chroma DC, 19..26: chroma AC), sized by ONE
+        // pass through the block coder with per-lane arguments -- the four kinds as four branches would run it four times
+        {
+            const int16_t *cp = L.dc16;
+            int maxn = 0, blk = 0, plane = 0;
+            bool luma = true;
+            if (lane == 0) {
+                maxn = 16;
+            } else if (lane <= 16) {
+                if (cbpL16) {
+                    cp = L.lv16[lane - 1];
+                    maxn = 15;
+                    blk = lane - 1;
+                }
+            } else if (lane <= 18) {
+                if (cbpC & 3) {
+                    cp = L.cdc[lane - 17];
+                    maxn = 4;
+                }
+            } else if (lane < 27) {
+                if (cbpC & 2) {
+                    plane = (lane - 19) >> 2;
+                    blk = (lane - 19) & 3;
+                    cp = L.cac[plane][blk];
+                    maxn = 15;
+                    luma = false;
+                }
+            }
+            if (maxn) {
+                const int nC = maxn == 4 ? -1 : nC_local(d, s, mb, luma, blk, plane, L.tc16, L.tcc, cbpL16, cbpC, stale_skip);
+                cavlc_block<false>(w, cp, maxn, nC);
+            }
         }
         bits16 = hb + wave_sum((int)w.bits);
     }
 
     // ---- phase 3: Intra4x4 mode costs on source samples (F/intra.cpp:1011-1048)
+    // 144 (block, mode) tasks in three rounds; a round holds four modes (16 lanes = 16 blocks each), so the predictor's
+    // switch runs 4 + 4 + 1 bodies instead of all nine in every round
     for (int rnd = 0; rnd < 3; rnd++) {
-        int task = rnd * 64 + lane;
-        if (task < 144) {
-            int blk = task / 9, mode = task % 9;
+        const int blk = lane & 15, mode = rnd * 4 + (lane >> 4);
+        const int task = blk * 9 + mode;
+        if (mode < 9) {
             int p[13], o[16], r[16], t[16], qv[16];
             fetch4(L, blk, lastcol, p);
             int key = 0x7fffffff;
@@ -340,12 +365,32 @@ __global__ __launch_bounds__(64) void k_intra_mb(FerDev d, int diag)
         bw_init<false>(w, nullptr, 0, 0);
         if (cbpL4 > 0 || cbpC > 0) {
             hb += 1;
-            if (lane < 16 && (cbpL4 & (1 << (lane >> 2))))
-                cavlc_block<false>(w, L.lv4[lane], 16, nC_local(d, s, mb, true, lane, 0, L.tc4, L.tcc, cbpL4, cbpC, false));
-            if ((lane == 17 || lane == 18) && (cbpC & 3)) cavlc_block<false>(w, L.cdc[lane - 17], 4, -1);
-            if (lane >= 19 && lane < 27 && (cbpC & 2)) {
-                int k = (lane - 19) >> 2, b = (lane - 19) & 3;
-                cavlc_block<false>(w, L.cac[k][b], 15, nC_local(d, s, mb, false, b, k, L.tc4, L.tcc, cbpL4, cbpC, false));
+            const int16_t *cp = L.lv4[0];
+            int maxn = 0, blk = 0, plane = 0;
+            bool luma = true;
+            if (lane < 16) {
+                if (cbpL4 & (1 << (lane >> 2))) {
+                    cp = L.lv4[lane];
+                    maxn = 16;
+                    blk = lane;
+                }
+            } else if (lane == 17 || lane == 18) {
+                if (cbpC & 3) {
+                    cp = L.cdc[lane - 17];
+                    maxn = 4;
+                }
+            } else if (lane >= 19 && lane < 27) {
+                if (cbpC & 2) {
+                    plane = (lane - 19) >> 2;
+                    blk = (lane - 19) & 3;
+                    cp = L.cac[plane][blk];
+                    maxn = 15;
+                    luma = false;
+                }
+            }
+            if (maxn) {
+                const int nC = maxn == 4 ? -1 : nC_local(d, s, mb, luma, blk, plane, L.tc4, L.tcc, cbpL4, cbpC, false);
+                cavlc_block<false>(w, cp, maxn, nC);
             }
         }
         bits4 = hb + wave_sum((int)w.bits);

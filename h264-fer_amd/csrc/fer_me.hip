@@ -664,9 +664,12 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
 // (step and side, see below); it returns true to end the
 // walk at once (wave-uniform).  Returns the count; jend = the step j the walk ended in.
 // tbl = 128 dwords of LDS private to the calling wavefront.
+// max_slice: slices with more records than this are not read (the caller bounds them otherwise) -- those of the steps
+// j > 0, and those of step 0 as well when skip0 is set.
 template <bool QUIRK, class SINK>
 __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int (&su)[5], const SuPk &sp, int sx, int sy, int lane,
-                                              uint32_t *tbl, int halt_cnt, int &jend, SINK sink)
+                                              uint32_t *tbl, int halt_cnt, int &jend, SINK sink, uint32_t max_slice = 0xffffffffu,
+                                              bool skip0 = false)
 {
     int tren = 0;
     jend = 180;  // last step whose buckets belong to the candidate set
@@ -782,7 +785,8 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
         // slice k = step * 2 + side in lane k < 32
         const int step = (lane >> 1) & 15, side = lane & 1;
         const uint32_t st = (uint32_t)__shfl((int)kb, step + (side ? 32 : 0)), en = (uint32_t)__shfl((int)kb, step + (side ? 48 : 16));
-        const uint32_t cnt = (lane < 32 && en > st) ? en - st : 0u;
+        uint32_t cnt = (lane < 32 && en > st) ? en - st : 0u;
+        if (cnt > max_slice && (j0 + step > 0 || skip0)) cnt = 0u;
         const int nb = (int)((cnt + 63u) >> 6);
         const int a_k = side ? su[0] + j0 + step : su[0] - (j0 + step);
         const uint32_t ja = ((uint32_t)(j0 + step) << 8) | ((uint32_t)(a_k & 0x7fff) << 16) | ((uint32_t)side << 31);
@@ -891,57 +895,73 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
         // A lower bound of the feature distance over the whole candidate set comes from the ranges the other four sums
         // take in each bucket (FerDev.brange): |s - k| >= the distance of s from the range of k.  It also tells whether
         // a candidate of distance 0 can exist at all (only in bucket su[0], and only if every range contains its sum).
+        // The smallest positive distance of the whole candidate set (what the ring scan of resolve_crowded stops on) is
+        // put together from two sides.  Slices of more than FER_BIG_SLICE records (the flat area itself) are not read
+        // again: their candidates are bounded from below by 5 |s_0 - a| -- |s_k - q_k| + |(s_0 - s_k) - (a - q_k)| >=
+        // |s_0 - a| for each of the four other sums -- and by the ranges those sums take in the bucket.  All other
+        // slices of the steps 0 .. J are small and are read: their exact smallest distance.  The same pass collects the
+        // candidates of distance 0 (bucket su[0] only; read whatever its size when its ranges admit distance 0).
         int zc = 0, dmin = 0x7fffffff;
-        bool zeros_possible = false;
+        bool skip0 = false;  // bucket su[0] is big and its ranges exclude distance 0: bounded, not read
         {
             const uint32_t *brs = d.brange + (size_t)s * 16384 * 8;
             const uint32_t *kol2p = d.kol2 + (size_t)s * 16384 * d.kt;
+            const int bt_lo = max(sx - 279, 0) >> d.ktw_shift, bt_hi = min(sx + 279, d.W - 1) >> d.ktw_shift;
             for (int b0 = -jend; b0 <= jend; b0 += 64) {
                 const int dj = b0 + lane;
                 const int a = su[0] + dj;
                 int lb = 0x7fffffff;
-                if (dj <= jend && a >= 0 && a < 16384 && kol2p[(size_t)(a + 1) * d.kt] != kol2p[(size_t)a * d.kt]) {  // a bucket with positions
-                    const uint4 hi = *(const uint4 *)(brs + (size_t)a * 8), lo = *(const uint4 *)(brs + (size_t)a * 8 + 4);
-                    const uint32_t h[4] = {hi.x, hi.y, hi.z, hi.w}, l[4] = {lo.x, lo.y, lo.z, lo.w};
-                    lb = iabs(dj);
-                    if (l[0] != 0) {  // ... and ranges (a large bucket); a small one is only known to be |dj| away
+                if (dj <= jend && a >= 0 && a < 16384) {
+                    // what the walk reads of the bucket: its positions in the column tiles the 280-diamond reaches
+                    const uint32_t sz = kol2p[(size_t)a * d.kt + bt_hi + 1] - kol2p[(size_t)a * d.kt + bt_lo];
+                    if (sz > (dj == 0 ? 0u : (uint32_t)FER_BIG_SLICE)) {
+                        const uint4 hi = *(const uint4 *)(brs + (size_t)a * 8), lo = *(const uint4 *)(brs + (size_t)a * 8 + 4);
+                        const uint32_t h[4] = {hi.x, hi.y, hi.z, hi.w}, l[4] = {lo.x, lo.y, lo.z, lo.w};
+                        lb = iabs(dj);
+                        if (l[0] != 0) {  // ... and ranges (a bucket of more than FER_BRANGE_MIN positions)
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int kmin = 65535 - (int)l[k], kmax = (int)h[k];
-                            const int s1 = su[k + 1], s2 = su[k + 1] + dj;  // |s_k - k_k| and |(s_0 - s_k) - (a - k_k)| = |k_k - (s_k + dj)|
-                            lb += max(max(kmin - s1, s1 - kmax), 0) + max(max(kmin - s2, s2 - kmax), 0);
+                            for (int k = 0; k < 4; k++) {
+                                const int kmin = 65535 - (int)l[k], kmax = (int)h[k];
+                                const int s1 = su[k + 1], s2 = su[k + 1] + dj;  // |s_k - k_k| and |(s_0 - s_k) - (a - k_k)| = |k_k - (s_k + dj)|
+                                lb += max(max(kmin - s1, s1 - kmax), 0) + max(max(kmin - s2, s2 - kmax), 0);
+                            }
+                        }
+                        lb = max(lb, 5 * iabs(dj));
+                        if (dj == 0) {  // bucket su[0] is read below unless it is big and cannot hold distance 0
+                            if (sz > (uint32_t)FER_BIG_SLICE && lb > 0)
+                                skip0 = true;
+                            else
+                                lb = 0x7fffffff;
                         }
                     }
-                    if (dj == 0 && lb == 0) zeros_possible = true;
                 }
                 dmin = min(dmin, lb);
             }
-            dmin = max(wave_min(dmin), 1);  // what the ring scan weighs has a distance of at least 1
-            zeros_possible = __any(zeros_possible);
+            dmin = wave_min(dmin);
+            skip0 = __any(skip0);
         }
-        if (zeros_possible) {
-            // Look for them.  When the walk ended in step 0 its second half -- bucket su[0] again, from the other side --
-            // holds the same positions as the first: it is not read, its candidates of distance 0 are the first
-            // half's, repeated.  (A scan that runs to the end also gives the exact smallest positive distance.)
+        {
+            // one more walk over the steps 0 .. J, without the big slices: candidates of distance 0 (step 0, first visit;
+            // the second visit of bucket su[0] repeats them) and the smallest positive distance of everything it reads
             int j2, dpos = 0x7fffffff;
-            bool complete = true;
-            walk_buckets(d, s, su, sp, sx, sy, lane, tbl, 0x7fffffff, j2, [&](bool ok, int rank, int rel, int D, uint32_t info) {
+            walk_buckets_q<false>(d, s, su, sp, sx, sy, lane, tbl, 0x7fffffff, j2, [&](bool ok, int rank, int rel, int D, uint32_t info) {
                 (void)rank;
-                if (jend == 0 && (info >> 31)) return true;
-                const bool z = ok && D == 0;
-                const unsigned long long mz = __ballot(z);
-                const int zr = zc + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mz, 0u));
-                if (z && zr < 33) out[zr] = make_int2(rel, 0);
-                zc += __popcll(mz);
+                const int j = (int)((info >> 8) & 255u);
+                if (j > jend) return true;
+                if (j == 0 && (info >> 31)) return false;  // (the second visit of bucket su[0]: the same records)
                 if (ok && D > 0) dpos = min(dpos, D);
-                if (zc >= 33) complete = false;
-                return zc >= 33;  // 33 candidates of distance 0 are the whole list: nothing else is needed
-            });
-            if (complete) {
-                dpos = wave_min(dpos);
-                if (dpos != 0x7fffffff) dmin = dpos;
-            }
-            if (jend == 0 && zc < 33) {  // the repeats of the second visit
+                if (j == 0) {
+                    const bool z = ok && D == 0;
+                    const unsigned long long mz = __ballot(z);
+                    const int zr = zc + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mz, 0u));
+                    if (z && zr < 33) out[zr] = make_int2(rel, 0);
+                    zc += __popcll(mz);
+                    if (zc >= 33) return true;  // 33 candidates of distance 0 are the whole list: nothing else is needed
+                }
+                return false;
+            }, (uint32_t)FER_BIG_SLICE, skip0);
+            dmin = max(min(dmin, wave_min(dpos)), 1);
+            if (zc < 33 && zc > 0) {  // the repeats of the second visit
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the list is read back
                 // (agent-scope load: served by L2, where the stores above have landed)
                 const unsigned long long ev = __hip_atomic_load((const unsigned long long *)&out[min(lane, 32)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1469,9 +1489,16 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
             if (skip) prevw = N.B;
         }
         if (part == 0 || !skip) {  // the same decision in both wavefronts: the barriers below are uniform
+#ifdef FER_PROBE
+            const long long tst = wall_clock64();
+#endif
             if (role == 0) {
                 int skipw, k1, xy1;
                 bool sk = resolve_stage1<WIN>(d, s, gx, gy, ln, cur, N, sel_lds, loc_lds, skipw, k1, xy1);
+#ifdef FER_PROBE
+                if (FER_DBGF(d, 128) && s == 0 && lane == 0)  // the slowest stage-1 call of the picture and where it was
+                    atomicMax((unsigned long long *)&d.timing[40], ((unsigned long long)(wall_clock64() - tst) << 24) | ((unsigned long long)gx << 12) | (unsigned long long)gy);
+#endif
                 PR_MARK(1)
                 __syncthreads();  // stage 2/3 results are in xch[0..3]
                 PR_MARK(2)
@@ -1516,6 +1543,14 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
             } else {
                 int k2, xy2, k3, xy3;
                 resolve_stage23<WIN>(d, s, gx, gy, ln, cur, N, sel_lds, k2, xy2, k3, xy3);
+#ifdef FER_PROBE
+                if (FER_DBGF(d, 128) && s == 0 && lane == 0) {
+                    const unsigned long long dt = (unsigned long long)(wall_clock64() - tst);
+                    atomicMax((unsigned long long *)&d.timing[41], (dt << 24) | ((unsigned long long)gx << 12) | (unsigned long long)gy);
+                    atomicAdd((unsigned long long *)&d.timing[42], dt);
+                    if (dt > 20000) atomicAdd((unsigned long long *)&d.timing[43], 1ull);  // calls of more than 200 us
+                }
+#endif
                 if (ln == 0) {
                     xch[0] = k2;
                     xch[1] = xy2;

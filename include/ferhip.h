@@ -165,6 +165,8 @@ int ferhip_inter_encoding(ferhip_ctx *c);
 #define FERHIP_BUF_REF 13     /* uint8  [S][W*H*3/2] reference picture buffers */
 #define FERHIP_BUF_TIMING 14  /* int64  [64] in-kernel wall-clock sums (10 ns units) when FER_DBG bit 7 is set */
 #define FERHIP_BUF_ST2N 15    /* int32  [S][nmb][4] stage-2 candidates of every 8x8 partition (before the list cap) */
+#define FERHIP_BUF_ST2 16     /* int32  [S][nmb][4][384][2] the candidates (position relative to the block, feature distance); a crowded
+                                 partition (count > 384) holds its summary instead: [40] = (last step, distance bound), [41] = (zeros, 0) */
 size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t cap);
 /* set the reference picture (dpb) directly, [S][W*H*3/2] host */
 int ferhip_set_reference(ferhip_ctx *c, const void *src);

@@ -7,6 +7,14 @@ import glob
 import json
 from pathlib import Path
 
+import os
+
+
+def newest(pattern):
+    """gpurun merges new files into gpurun_out/ without removing those of earlier runs: take the latest"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 root = Path(__file__).resolve().parent.parent
 go = root / "gpurun_out" / "r02"
 prof = root / "profiles"
@@ -21,7 +29,7 @@ def first_json(path):
 
 
 def stats_table(d, title, cmd, bl):
-    rows = list(csv.DictReader(open(glob.glob(str(go / d / "*/*_kernel_stats.csv"))[0])))
+    rows = list(csv.DictReader(open(newest(str(go / d / "*/*_kernel_stats.csv")))))
     out = [f"## {title}", "", f"`{cmd}`", "",
            "(bench line of the same run: %.2f M MB/s, roofline kernel `%s`: average launch %.1f us by HIP events inside bench.py)"
            % (bl["value"] / 1e6, bl["roofline"]["kernel"], bl["roofline"]["avg_launch_us"]), "",
@@ -42,15 +50,15 @@ b2 = first_json(go / "bench_prof2.json")
 b1 = first_json(go / "bench_prof1.json")
 (prof / "r02_bench_prof.json").write_text(json.dumps({"two_contexts": b2, "one_context": b1}) + "\n")
 md = ["# Round 2 — rocprofv3 kernel summaries of the benchmark command", "",
-      "1080p IPPP, 128 streams, one warm-up GOP + one timed GOP (+ the output-check GOP); MI355X.  The `at::native` kernels belong "
+      "1080p IPPP, one warm-up GOP + one timed GOP (+ the output-check GOP); MI355X.  The `at::native` kernels belong "
       "to the synthetic-input generator.", ""]
-md += stats_table("stats2", "Default: two contexts of 64 streams",
+md += stats_table("stats2", "Default: 256 streams in two contexts of 128",
                   "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --secondary 0 --e2e 0", b2)
 md += ["", "With two contexts the kernels of one context share the CUs with the other's: a kernel's duration includes that "
        "(the streaming kernels of the reference preparation stretch most), and the per-kernel totals add up to more than the wall "
        "time.  The isolated table follows.", ""]
 md += stats_table("stats1", "One context of 128 streams (every kernel alone on the GPU)",
-                  "... bench.py --steps 1 --warmup 1 --cpu-frames 0 --secondary 0 --e2e 0 --contexts 1", b1)
+                  "... bench.py --steps 1 --warmup 1 --cpu-frames 0 --secondary 0 --e2e 0 --contexts 1 --streams 128", b1)
 (prof / "r02_kernel_stats_bench.md").write_text("\n".join(md) + "\n")
 
 
@@ -69,8 +77,8 @@ def load(path, counter):
     return agg, cnt
 
 
-fa, fc = load(glob.glob(str(go / "pmc_fetch/*/*_counter_collection.csv"))[0], "FETCH_SIZE")
-wa, wc = load(glob.glob(str(go / "pmc_write/*/*_counter_collection.csv"))[0], "WRITE_SIZE")
+fa, fc = load(newest(str(go / "pmc_fetch/*/*_counter_collection.csv")), "FETCH_SIZE")
+wa, wc = load(newest(str(go / "pmc_write/*/*_counter_collection.csv")), "WRITE_SIZE")
 S, nmb = 16, 8040
 alg = {"k_interp": 4352, "k_feat0": 256 + 256 * 30, "k_me_pre": 528, "k_me_walk": 528, "k_me_resolve": 528, "k_p_resid": 1152,
        "k_intra_mb": 768, "k_cavlc": 800, "k_frame_sad": 512, "k_rs_scatter": 256 * 33}
@@ -114,7 +122,7 @@ tj = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 seen = set()
-for r in csv.DictReader(open(glob.glob(str(go / "pmc_sq/*/*_counter_collection.csv"))[0])):
+for r in csv.DictReader(open(newest(str(go / "pmc_sq/*/*_counter_collection.csv")))):
     k = r["Kernel_Name"].split("(")[0].replace("void ", "")
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if (k, r["Dispatch_Id"]) not in seen:
@@ -135,8 +143,13 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["SQ_WAVE_CYCLES"]):
     md.append("| `%s` | %d | %.0f | %.0f | %.1f | %.1f | %.1f | %.1f |" % (
         k[:30], n, v["SQ_INSTS_VALU"] / n / parts, v["SQ_INSTS_SALU"] / n / parts, 100 * v["SQ_ACTIVE_INST_VALU"] / wcy,
         100 * v["SQ_ACTIVE_INST_ANY"] / wcy, 100 * v["SQ_WAIT_ANY"] / wcy, 100 * v["SQ_WAIT_INST_ANY"] / wcy))
-md += ["", "The scalar unit is one per CU: `k_me_walk` at 1 830 scalar instructions per partition issued 0.9 of them per CU cycle -- "
-       "it was scalar-issue bound, which is why its control flow moved into the lanes (batch tables) this round."]
+md += ["", "For a per-macroblock kernel multiply by 4 (k_p_resid: the line above x 4 wave instructions per macroblock); `k_intra_mb` is "
+       "one dispatch per anti-diagonal: its per-macroblock count is the line x 4 x 252 dispatches of a picture.",
+       "", "The scalar unit is one per CU: `k_me_walk` at 1 830 scalar instructions per partition issued 0.9 of them per CU cycle -- "
+       "it was scalar-issue bound, which is why its control flow moved into the lanes (batch tables) this round.  At the counts above "
+       "the three motion kernels are VALU-issue bound: instructions x partitions x 4 cycles / (1024 SIMDs x clock) is 85-100 % of "
+       "the measured duration of `k_me_pre` and `k_me_walk`, and about 50 % for `k_me_resolve` (whose row chain keeps a fifth of its "
+       "workgroups waiting at the start and end of every stream group)."]
 (prof / "r02_sq_counters.md").write_text("\n".join(md) + "\n")
 print("bench 2ctx", b2["value"], "1ctx", b1["value"])
 print("traffic", tj["bytes_per_mb"])
