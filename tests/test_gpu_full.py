@@ -123,11 +123,18 @@ def test_other_window_sizes(pkg, fo, window):
     _check_against_oracle(pkg, fo, 352, 288, 3, 2, qp=20, window=window, intra_every=30, check_streams=(0, 1))
 
 
-@pytest.mark.parametrize("kind", ["flat", "half", "bars"])
-def test_flat_areas_overflow_the_candidate_lists(pkg, fo, kind):
+@pytest.mark.parametrize("kind,W,H", [("flat", 352, 288), ("half", 352, 288), ("bars", 352, 288), ("half", 1920, 64), ("thirds", 1920, 48),
+                                      ("drift", 352, 288), ("drift", 1920, 64), ("drift", 1280, 96)])
+def test_flat_areas_overflow_the_candidate_lists(pkg, fo, kind, W, H):
     """Large flat areas: thousands of positions share one feature vector, the stage-2 candidate set of a partition
-    outgrows what k_me_walk keeps and k_me_resolve walks the buckets again with an exact running top-33."""
-    W, H, T = 352, 288, 3
+    outgrows what k_me_walk keeps; k_me_resolve then looks for the winners around the predictor (resolve_crowded) with
+    the summary k_me_walk leaves (last step, distance bound, candidates of distance 0).  The wide, low pictures make the
+    column range of the 280-diamond matter: partitions deep inside the flat area never see the textured part's
+    positions of the same sums, partitions near the border do (the bound is then small and the ring scan long).
+    "drift": the flat value moves by 2 per picture and MAXDIFF is 1, so the flat macroblocks are NOT P_Skip and every flat
+    partition goes through the crowded stage 2 with the flat area of the previous picture 128 buckets away."""
+    T = 3
+    maxdiff = 1 if kind == "drift" else 3
     frames = []
     for t in range(T):
         f = pkg.gen_frame(W, H, t, 77, 2).copy()
@@ -136,16 +143,21 @@ def test_flat_areas_overflow_the_candidate_lists(pkg, fo, kind):
             y[:] = 128
         elif kind == "half":
             y[:, : W // 2] = 100
+        elif kind == "drift":
+            y[:, : W // 2] = 100 + 2 * t
+        elif kind == "thirds":  # two flat areas of different values around a textured one
+            y[:, : W // 3] = 60
+            y[:, 2 * W // 3:] = 200
         else:  # letterbox
             y[:32] = 16
             y[-32:] = 16
         frames.append(f)
     frames = np.stack(frames)[:, None]
-    g = pkg.FerHip(W, H, 1, qp=20, window=32, maxdiff=3, intra_every=30)
+    g = pkg.FerHip(W, H, 1, qp=20, window=32, maxdiff=maxdiff, intra_every=30)
     streams, rec = g.encode_streams(frames, want_recon=True)
     assert g.status() == [0]
     g.close()
-    o = fo.Oracle(W, H, qp=20, window=32, maxdiff=3, intra_every=30)
+    o = fo.Oracle(W, H, qp=20, window=32, maxdiff=maxdiff, intra_every=30)
     ref, ref_rec = o.encode_stream(frames[:, 0])
     o.close()
     assert streams[0] == ref and np.array_equal(rec[:, 0], ref_rec)
