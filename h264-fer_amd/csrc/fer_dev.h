@@ -28,6 +28,10 @@
 #define FER_IP_R 16
 #define FER_IP_T 4
 #define FER_IP_B 12
+#define FER_BIGS 3            // big bucket slices of a crowded partition that are described by class (more = the general bound)
+#define FER_P2_CAP 320        // listed candidates of a crowded partition (slots 64 .. 383 of its stage-2 list)
+#define FER_OUTL 512          // outliers of a big bucket that are listed (more = the bucket has no modal class)
+#define FER_OSLOTS 256        // big buckets of a stream that get an outlier list
 #define FER_BRANGE_MIN 1024  // buckets with more positions than this get feature ranges (FerDev.brange)
 #define FER_ST2_CAP 384  // stage-2 candidates kept per 8x8 partition
 #define FER_BIG_SLICE 1024  // records of one bucket inside a partition's column range beyond which k_me_walk bounds instead of reading
@@ -67,6 +71,12 @@ struct FerDev {
     // 65535 - k1..k4 (so that one atomicMax and a zero fill serve both ends), for buckets of more than FER_BRANGE_MIN
     // positions; all zero = no ranges.  Lower bounds of the feature distance for crowded partitions (k_me_walk).
     uint32_t *brange;
+    // A bucket of more than FER_BRANGE_MIN positions is usually ONE flat area plus a few stray positions of the same
+    // sum: bmodal[S][16384][4] = the two feature dwords of the record in the middle of the bucket (its "modal class"),
+    // the number of records that differ from it, the bucket's outlier list (the big buckets are numbered in bucket
+    // order; 0xffffffff = none); boutl[S][FER_OSLOTS][FER_OUTL] = the sorted-array indices of those records (any order).  With at most FER_OUTL outliers the class is bounded EXACTLY by its one
+    // feature distance and the outliers are listed as candidates of their own (k_me_walk, resolve_crowded).
+    uint32_t *bmodal, *boutl;
     int *zero_cnt;       // [S] positions of the reference picture whose 8x8 sum is 0 (see "bucket 0" in k_sort_finish)
     // per-MB side information (a20)
     int *mb_type;        // [S][nmb]

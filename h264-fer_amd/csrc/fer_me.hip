@@ -903,6 +903,11 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
         // candidates of distance 0 (bucket su[0] only; read whatever its size when its ranges admit distance 0).
         int zc = 0, dmin = 0x7fffffff;
         bool skip0 = false;  // bucket su[0] is big and its ranges exclude distance 0: bounded, not read
+        // the big slices (at most FER_BIGS of them are described; more = the general bound only)
+        int nbig = 0, bigA[FER_BIGS], bigDj[FER_BIGS];
+        bool fallback = false;
+#pragma unroll
+        for (int q = 0; q < FER_BIGS; q++) bigA[q] = bigDj[q] = 0;
         {
             const uint32_t *brs = d.brange + (size_t)s * 16384 * 8;
             const uint32_t *kol2p = d.kol2 + (size_t)s * 16384 * d.kt;
@@ -911,38 +916,115 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
                 const int dj = b0 + lane;
                 const int a = su[0] + dj;
                 int lb = 0x7fffffff;
+                bool big = false;
                 if (dj <= jend && a >= 0 && a < 16384) {
                     // what the walk reads of the bucket: its positions in the column tiles the 280-diamond reaches
                     const uint32_t sz = kol2p[(size_t)a * d.kt + bt_hi + 1] - kol2p[(size_t)a * d.kt + bt_lo];
+                    big = sz > (uint32_t)FER_BIG_SLICE;
                     if (sz > (dj == 0 ? 0u : (uint32_t)FER_BIG_SLICE)) {
                         const uint4 hi = *(const uint4 *)(brs + (size_t)a * 8), lo = *(const uint4 *)(brs + (size_t)a * 8 + 4);
                         const uint32_t h[4] = {hi.x, hi.y, hi.z, hi.w}, l[4] = {lo.x, lo.y, lo.z, lo.w};
                         lb = iabs(dj);
                         if (l[0] != 0) {  // ... and ranges (a bucket of more than FER_BRANGE_MIN positions)
 #pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                const int kmin = 65535 - (int)l[k], kmax = (int)h[k];
-                                const int s1 = su[k + 1], s2 = su[k + 1] + dj;  // |s_k - k_k| and |(s_0 - s_k) - (a - k_k)| = |k_k - (s_k + dj)|
+                            for (int q = 0; q < 4; q++) {
+                                const int kmin = 65535 - (int)l[q], kmax = (int)h[q];
+                                const int s1 = su[q + 1], s2 = su[q + 1] + dj;  // |s_k - k_k| and |(s_0 - s_k) - (a - k_k)| = |k_k - (s_k + dj)|
                                 lb += max(max(kmin - s1, s1 - kmax), 0) + max(max(kmin - s2, s2 - kmax), 0);
                             }
                         }
                         lb = max(lb, 5 * iabs(dj));
-                        if (dj == 0) {  // bucket su[0] is read below unless it is big and cannot hold distance 0
-                            if (sz > (uint32_t)FER_BIG_SLICE && lb > 0)
+                        if (dj == 0) {  // bucket su[0] is read below (all of it) unless it is big and cannot hold distance 0
+                            if (big && lb > 0) {
                                 skip0 = true;
-                            else
+                            } else {
                                 lb = 0x7fffffff;
+                                big = false;
+                            }
                         }
                     }
                 }
                 dmin = min(dmin, lb);
+                unsigned long long bm = __ballot(big);
+                while (bm) {
+                    const int src = __ffsll((long long)bm) - 1;
+                    bm &= bm - 1;
+                    if (nbig < FER_BIGS) {
+#pragma unroll
+                        for (int q = 0; q < FER_BIGS; q++)
+                            if (q == nbig) {
+                                bigA[q] = lane_bcast(a, src);
+                                bigDj[q] = lane_bcast(dj, src);
+                            }
+                        nbig++;
+                    } else {
+                        fallback = true;
+                    }
+                }
             }
             dmin = wave_min(dmin);
             skip0 = __any(skip0);
         }
+        // candidates listed for resolve_crowded (slots 64 .. 383 of the partition's list): everything of the small slices,
+        // and the outliers of the big ones
+        int np2 = 0;
+        const uint32_t g0_ = (uint32_t)s * (uint32_t)(d.W * d.H);
+        auto p2_add = [&](bool take, int rel, uint32_t D, int j, int side) {
+            const unsigned long long mt = __ballot(take);
+            const int pos = np2 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mt, 0u));
+            if (take && pos < FER_P2_CAP) out[64 + pos] = make_int2(rel, (int)(D | ((uint32_t)j << 20) | ((uint32_t)side << 28)));
+            np2 += __popcll(mt);
+        };
+        // The big slices: the modal class of the bucket (FerDev.bmodal) has ONE feature distance, which bounds it exactly;
+        // its outliers are candidates of their own.
+        int dminN = 0x7fffffff;
+        int bigD[FER_BIGS];
+#pragma unroll
+        for (int q = 0; q < FER_BIGS; q++) bigD[q] = 0x7fffffff;
+        const uint32_t sxy_ = ((uint32_t)sx << 16) | (uint32_t)sy;
+#pragma unroll
+        for (int q = 0; q < FER_BIGS; q++) {
+            if (q < nbig && !fallback) {
+                const uint32_t *bmq = d.bmodal + ((size_t)s * 16384 + bigA[q]) * 4;
+                const uint32_t m1 = bmq[0], m2 = bmq[1], nout = bmq[2];
+                const int jq = iabs(bigDj[q]), sideq = bigDj[q] > 0 ? 1 : 0;
+                const uint32_t aa = (uint32_t)bigA[q] * 0x10001u;
+                auto dist_of = [&](uint32_t r1, uint32_t r2) {
+                    uint32_t D = __builtin_amdgcn_sad_u16(r1, sp.s12, (uint32_t)jq);
+                    D = __builtin_amdgcn_sad_u16(r2, sp.s34, D);
+                    D = __builtin_amdgcn_sad_u16(pk_sub16(aa, r1), sp.e12, D);
+                    return __builtin_amdgcn_sad_u16(pk_sub16(aa, r2), sp.e34, D);
+                };
+                auto halves_ok = [&](uint32_t r1) {
+                    const uint32_t e12 = pk_abs16(pk_sub16(r1, sp.s12));
+                    return (pk_sub16(e12, 0x00640064u) & 0x80008000u) == 0x80008000u;
+                };
+                if (nout > FER_OUTL) {
+                    fallback = true;
+                } else {
+                    const uint32_t DM = dist_of(m1, m2);
+                    const bool members = halves_ok(m1);  // the half-sum test of the walk is the same for the whole class
+                    bigD[q] = members && DM > 0 ? (int)DM : 0x7fffffff;
+                    dminN = min(dminN, bigD[q]);
+                    // the outliers, 64 to a batch
+                    const uint32_t *ol = d.boutl + ((size_t)s * FER_OSLOTS + bmq[3]) * FER_OUTL;
+                    for (uint32_t o0 = 0; o0 < nout; o0 += 64) {
+                        const bool lv = o0 + (uint32_t)lane < nout;
+                        const uint32_t idx = lv ? ol[o0 + lane] : g0_;
+                        const uint32_t *rec = d.sort_rec + (size_t)idx * 3;
+                        const uint32_t r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                        const uint32_t D = dist_of(r1, r2);
+                        const bool take = lv && __builtin_amdgcn_sad_u16(r0, sxy_, 0u) < 280u && halves_ok(r1) && D > 0 && D != DM;
+                        p2_add(take, (int)pk_sub16(r0, sxy_), D, jq, sideq);
+                    }
+                    // (an outlier at distance 0 is found by the read of bucket su[0] below: its ranges admit 0 then)
+                }
+            }
+        }
         {
             // one more walk over the steps 0 .. J, without the big slices: candidates of distance 0 (step 0, first visit;
-            // the second visit of bucket su[0] repeats them) and the smallest positive distance of everything it reads
+            // the second visit of bucket su[0] repeats them), every other candidate it reads -> the list, and the
+            // smallest positive distance of those (the general bound)
             int j2, dpos = 0x7fffffff;
             walk_buckets_q<false>(d, s, su, sp, sx, sy, lane, tbl, 0x7fffffff, j2, [&](bool ok, int rank, int rel, int D, uint32_t info) {
                 (void)rank;
@@ -950,6 +1032,7 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
                 if (j > jend) return true;
                 if (j == 0 && (info >> 31)) return false;  // (the second visit of bucket su[0]: the same records)
                 if (ok && D > 0) dpos = min(dpos, D);
+                p2_add(ok && D > 0, rel, (uint32_t)D, j, (int)(info >> 31));
                 if (j == 0) {
                     const bool z = ok && D == 0;
                     const unsigned long long mz = __ballot(z);
@@ -970,9 +1053,13 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
                 zc = min(2 * zc, 33);
             }
         }
+        if (np2 > FER_P2_CAP) fallback = true;
         if (lane == 0) {
             out[40] = make_int2(jend, dmin);
-            out[41] = make_int2(min(zc, 33), 0);
+            out[41] = make_int2(min(zc, 33), (int)((uint32_t)min(np2, FER_P2_CAP) | ((uint32_t)nbig << 16) | (fallback ? 0x40000000u : 0u)));
+#pragma unroll
+            for (int q = 0; q < FER_BIGS; q++) out[42 + q] = make_int2(bigA[q], bigD[q]);
+            out[46] = make_int2(dminN, 0);
         }
     }
     if (lane == 0) d.st2n[pidx] = tren;
@@ -1051,11 +1138,7 @@ __device__ __forceinline__ void res_prefetch(const FerDev &d, int s, int gx, int
         const int2 *c2 = (const int2 *)(d.st2 + pidx * FER_ST2_CAP * 2);
 #pragma unroll
         for (int u = 0; u < FER_ST2_CAP / 64; u++) p.e2[u] = c2[u * 64 + lane];  // slots >= n2 hold stale data, masked later
-        p.z = p.e2[0];
-        if (p.n2raw > FER_ST2_CAP) {  // the summary of a crowded partition sits in slots 40 and 41 (wave-uniform)
-            p.e2[0] = c2[40];
-            p.e2[1] = c2[41];
-        }
+        p.z = p.e2[0];  // (a crowded partition: slots 0 .. 32 = its candidates of distance 0, 40 .. 46 = its summary, 64 .. = its list)
         const int *c3 = d.st3 + pidx * 33 * 3;
         const int l3 = min(lane, 32);
         p.c3x = c3[l3 * 3];
@@ -1261,7 +1344,18 @@ __device__ __forceinline__ void resolve_crowded(const FerDev &d, int s, int sx, 
     const int W = d.W, H = d.H;
     const uint16_t *F0 = d.feat0 + (size_t)s * 6 * d.ysz;
     const SuPk sp = su_pack(P.su);
-    const int J = P.e2[0].x, dmin = P.e2[0].y, zc = P.e2[1].x;  // summary of k_me_walk (slots 40, 41 of the list)
+    // summary of k_me_walk (slots 40 .. 46 of the list, held by those lanes of the first batch)
+    const int J = lane_bcast(P.e2[0].x, 40), zc = lane_bcast(P.e2[0].x, 41);
+    const uint32_t fl = (uint32_t)lane_bcast(P.e2[0].y, 41);
+    const bool classes = (fl & 0x40000000u) == 0;  // big slices described by class, everything else listed
+    const int np2 = classes ? (int)(fl & 0xffffu) : 0, nbig = classes ? (int)((fl >> 16) & 15u) : 0;
+    const int dmin = classes ? lane_bcast(P.e2[0].x, 46) : lane_bcast(P.e2[0].y, 40);
+    int bigA[FER_BIGS], bigD[FER_BIGS];
+#pragma unroll
+    for (int q = 0; q < FER_BIGS; q++) {
+        bigA[q] = lane_bcast(P.e2[0].x, 42 + q);
+        bigD[q] = lane_bcast(P.e2[0].y, 42 + q);
+    }
     CList L;
     L.m = INF_M;
     L.ak = 0xffffffffu;
@@ -1272,6 +1366,24 @@ __device__ __forceinline__ void resolve_crowded(const FerDev &d, int s, int sx, 
         L.m = 0;
         L.ak = (unsigned)lane;  // only their order matters: nothing else has metric 0
         L.xy = pack_xy(tx * 4, ty * 4);
+    }
+    if (zc < 33) {
+#pragma unroll
+        for (int u = 1; u < FER_ST2_CAP / 64; u++) {  // the listed candidates: position relative to the block, D | j << 20 | side << 28
+            if ((u - 1) * 64 < np2) {
+                const bool on = (u - 1) * 64 + lane < np2;
+                const int rel = P.e2[u].x;
+                const uint32_t pk = (uint32_t)P.e2[u].y;
+                const int tx = rel >> 16, ty = (int)(short)(rel & 0xffff);
+                const int D = (int)(pk & 0xfffffu), j = (int)((pk >> 20) & 255u);
+                const unsigned side = (pk >> 28) & 1u;
+                const int m = (iabs(tx - genx) + iabs(ty - geny) + 4) * D;
+                const unsigned akey = ((unsigned)j << 21) | ((unsigned)(tx + 280) << 10) | (unsigned)(ty + 280);
+                const int xy = pack_xy(tx * 4, ty * 4);
+                cl_insert(L, lane, on, m, akey | (side << 20), xy);
+                if (__any(on && j == 0)) cl_insert(L, lane, on && j == 0, m, akey | (1u << 20), xy);  // the second visit of bucket su[0]
+            }
+        }
     }
     if (zc < 33 && dmin != 0x7fffffff) {
         const int cx = sx + genx, cy = sy + geny;  // the ring centre, picture coordinates
@@ -1302,7 +1414,13 @@ __device__ __forceinline__ void resolve_crowded(const FerDev &d, int s, int sx, 
             const int tx = px - sx, ty = py - sy;
             const bool member = inpic && j <= J && iabs(tx) + iabs(ty) < 280 && iabs(kk1 - P.su[1]) < 100 && iabs(kk2 - P.su[2]) < 100;
             const int D = feat_dist_w(a, b, c, sp);
-            const bool take = member && D > 0;  // distance 0 is in the list already
+            bool take = member && D > 0;  // distance 0 is in the list already
+            if (classes) {  // only the modal classes of the big slices: everything else was listed
+                bool cls = false;
+#pragma unroll
+                for (int q = 0; q < FER_BIGS; q++) cls = cls || (q < nbig && kk0 == bigA[q] && D == bigD[q]);
+                take = take && cls;
+            }
             const int m = (r + 4) * D;
             const int side = kk0 > P.su[0] ? 1 : 0;
             const unsigned akey = ((unsigned)j << 21) | ((unsigned)(tx + 280) << 10) | (unsigned)(ty + 280);

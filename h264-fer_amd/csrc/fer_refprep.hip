@@ -562,6 +562,87 @@ __global__ __launch_bounds__(256) void k_bucket_ranges(FerDev d, const uint16_t 
     }
 }
 
+// Numbers the big buckets of a stream (more than FER_BRANGE_MIN positions) in bucket order: the first FER_OSLOTS of them
+// get an outlier list.  One workgroup per stream, 64 buckets per thread.
+__global__ __launch_bounds__(256) void k_bucket_slots(FerDev d)
+{
+    __shared__ int part[256];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (d.hdr[s * 4 + 3] != 0 || d.zero_cnt[s] != 0) return;
+    const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * d.kt;
+    int cnt = 0;
+    for (int a = tid * 64; a < tid * 64 + 64; a++) cnt += kol2[(size_t)(a + 1) * d.kt] - kol2[(size_t)a * d.kt] > FER_BRANGE_MIN;
+    part[tid] = cnt;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int slot = part[tid] - cnt;
+    for (int a = tid * 64; a < tid * 64 + 64; a++) {
+        const bool big = kol2[(size_t)(a + 1) * d.kt] - kol2[(size_t)a * d.kt] > FER_BRANGE_MIN;
+        d.bmodal[((size_t)s * 16384 + a) * 4 + 3] = big && slot < FER_OSLOTS ? (uint32_t)slot : 0xffffffffu;
+        slot += big;
+    }
+}
+
+// Modal class and outliers of the big buckets (FerDev.bmodal / boutl): one thread per sorted record.  A wavefront usually
+// sits inside one bucket; it counts its outliers with one atomic per bucket it touches and stops adding once the
+// bucket is known to have too many.
+__global__ __launch_bounds__(256) void k_bucket_modal(FerDev d, const uint16_t *skey)
+{
+    const int s = blockIdx.y;
+    if (d.hdr[s * 4 + 3] != 0 || d.zero_cnt[s] != 0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = d.W * d.H;
+    const size_t g0 = (size_t)s * n;
+    const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * d.kt;
+    const bool in = i < n;
+    const int key = in ? (int)skey[g0 + i] : -1;
+    uint32_t bs = 0, be = 0;
+    if (in) {
+        bs = kol2[(size_t)key * d.kt];
+        be = kol2[(size_t)(key + 1) * d.kt];
+    }
+    const bool on = in && be - bs > FER_BRANGE_MIN;
+    if (!__any(on)) return;
+    bool outl = false;
+    if (on) {
+        const uint32_t *m = d.sort_rec + (size_t)(bs + (be - bs) / 2) * 3, *r = d.sort_rec + (g0 + i) * 3;
+        const uint32_t m1 = m[1], m2 = m[2];
+        outl = r[1] != m1 || r[2] != m2;
+        if (g0 + i == bs) {
+            uint32_t *bm = d.bmodal + ((size_t)s * 16384 + key) * 4;
+            bm[0] = m1;
+            bm[1] = m2;
+        }
+    }
+    unsigned long long todo = __ballot(outl);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int kcur = __builtin_amdgcn_readlane(key, __ffsll((long long)todo) - 1);
+        const bool mine = outl && key == kcur;
+        const unsigned long long mm = __ballot(mine);
+        todo &= ~mm;
+        uint32_t *bm = d.bmodal + ((size_t)s * 16384 + kcur) * 4;
+        const uint32_t slot = bm[3];  // (written by k_bucket_slots)
+        uint32_t base = FER_OUTL + 1;
+        if (lane == 0) {
+            if (slot == 0xffffffffu)
+                bm[2] = FER_OUTL + 1;  // no list for this bucket: it counts as one without a modal class
+            else if (__hip_atomic_load(bm + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= FER_OUTL)
+                base = atomicAdd(bm + 2, (uint32_t)__popcll(mm));
+        }
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (mine && slot != 0xffffffffu) {
+            const uint32_t k = base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+            if (k < FER_OUTL) d.boutl[((size_t)s * FER_OSLOTS + slot) * FER_OUTL + k] = (uint32_t)(g0 + i);
+        }
+    }
+}
+
 // Bucket 0.  The reference's counting sort (F/moestimation.cpp:153-172) leaves bucket 0 out of its prefix sum: with
 // n0 positions of sum 0, every other bucket starts n0 places early (the sorted array is the other positions from 0,
 // its last n0 places keep what the previous picture left there), the k-th sum-0 position is written to place n0 + k,
@@ -649,6 +730,9 @@ void fer_launch_sort_finish(const FerDev &d, FerSortTmp &t, hipStream_t st)
     hipMemsetAsync(d.brange, 0, (size_t)d.S * 16384 * 8 * sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_sort_index, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
     hipLaunchKernelGGL(k_bucket_ranges, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
+    hipMemsetAsync(d.bmodal, 0, (size_t)d.S * 16384 * 4 * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_bucket_slots, dim3(d.S), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_bucket_modal, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
     hipLaunchKernelGGL(k_sort_quirk, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.rec_tmp);
 }
 
