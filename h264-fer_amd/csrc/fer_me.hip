@@ -1460,11 +1460,15 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
     predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
     const int genx = mvpx >> 2, geny = mvpy >> 2;
     WList L2;
-    if (P.n2raw > FER_ST2_CAP && d.zero_cnt[s] == 0) {
+    // a crowded partition without a big slice whose candidates did not fit the list (a few hundred of them, all in small
+    // slices): reading them again costs little
+    const uint32_t cfl = (uint32_t)lane_bcast(P.e2[0].y, 41);
+    const bool rewalk = (cfl & 0x40000000u) != 0 && ((cfl >> 16) & 15u) == 0;
+    if (P.n2raw > FER_ST2_CAP && d.zero_cnt[s] == 0 && !rewalk) {
         resolve_crowded(d, s, sx, sy, lane, P, genx, geny, L2);
     } else if (P.n2raw > FER_ST2_CAP) {
-        // crowded AND the reference's mis-filed bucket layout (black areas): walk the buckets again, now that the
-        // predictor is known, through an exact running top-33 (ordered insertion = the reference's own list update)
+        // crowded AND the reference's mis-filed bucket layout (black areas), or the case above: walk the buckets again,
+        // now that the predictor is known, through an exact running top-33 (ordered insertion = the reference's own list update)
         L2.m = INF_M;
         L2.xy = 0;
         const SuPk sp = su_pack(P.su);

@@ -46,3 +46,9 @@ if int(os.environ.get("FER_DBG", "0")) & 128:  # a -DFER_PROBE build: where the 
         v = int(t[k]) & 0xffffffffffffffff
         print(nm, "%.1f us at partition column %d row %d" % ((v >> 24) / 100, (v >> 12) & 4095, v & 4095))
     print("stage-2/3 total %.1f ms, calls over 200 us: %d" % (int(t[42]) / 1e5, int(t[43])))
+fl = st2[cr, 41, 1]
+print("crowded: general-bound fallback", int(((fl >> 30) & 1).sum()), " listed candidates: median", int(np.median(fl & 0xffff)), "max", int((fl & 0xffff).max()),
+      " big slices hist", np.bincount((fl >> 16) & 15, minlength=5))
+fb = np.nonzero(cr)[0][((fl >> 30) & 1) == 1]
+if fb.size:
+    print("fallback partitions: x", np.unique(((fb // 4) % nm) * 16 + (fb % 4 & 1) * 8)[:40], " ST2N", n[fb][:10], " summary of the first:", st2[fb[0], 40:47].tolist())
