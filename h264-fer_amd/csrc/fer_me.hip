@@ -666,10 +666,15 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
 // tbl = 128 dwords of LDS private to the calling wavefront.
 // max_slice: slices with more records than this are not read (the caller bounds them otherwise) -- those of the steps
 // j > 0, and those of step 0 as well when skip0 is set.
-template <bool QUIRK, class SINK>
+// probe(bucket) may return a number of candidates the slice of that bucket is KNOWN to hold (0 = unknown): when that
+// alone takes the count past halt_cnt the slice is not read (only walks that ask "is this partition crowded" pass one).
+struct NoProbe {
+    __device__ __forceinline__ int operator()(int) const { return 0; }
+};
+template <bool QUIRK, class SINK, class PROBE = NoProbe>
 __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int (&su)[5], const SuPk &sp, int sx, int sy, int lane,
                                               uint32_t *tbl, int halt_cnt, int &jend, SINK sink, uint32_t max_slice = 0xffffffffu,
-                                              bool skip0 = false)
+                                              bool skip0 = false, PROBE probe = PROBE())
 {
     int tren = 0;
     jend = 180;  // last step whose buckets belong to the candidate set
@@ -823,6 +828,14 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
                 const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)st, k), kc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, k);
                 const uint32_t kja = (uint32_t)__builtin_amdgcn_readlane((int)ja, k);
                 const int knb = (int)((kc + 63u) >> 6);
+                if (kc > (uint32_t)FER_BIG_SLICE) {
+                    const int known = probe((int)((kja >> 16) & 0x7fffu));
+                    if (known > 0 && tren + known > halt_cnt) {
+                        tren += known;
+                        jend = j0 + (k >> 1);
+                        return tren;
+                    }
+                }
                 for (int b0 = 0; b0 < knb; b0 += 62) {
                     const int m = min(62, knb - b0);
                     const uint32_t off = 64u * (uint32_t)(b0 + lane);
@@ -839,14 +852,14 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
     return tren;
 }
 
-template <class SINK>
+template <class SINK, class PROBE = NoProbe>
 __device__ __forceinline__ int walk_buckets(const FerDev &d, int s, const int (&su)[5], const SuPk &sp, int sx, int sy, int lane,
-                                            uint32_t *tbl, int halt_cnt, int &jend, SINK sink)
+                                            uint32_t *tbl, int halt_cnt, int &jend, SINK sink, PROBE probe = PROBE())
 {
     jend = 0;
     if (d.basic || FER_DBGF(d, 8)) return 0;
     if (d.zero_cnt[s] > 0) return walk_buckets_q<true>(d, s, su, sp, sx, sy, lane, tbl, 0x7fffffff, jend, sink);  // (the exact slow path needs every candidate)
-    return walk_buckets_q<false>(d, s, su, sp, sx, sy, lane, tbl, halt_cnt, jend, sink);
+    return walk_buckets_q<false>(d, s, su, sp, sx, sy, lane, tbl, halt_cnt, jend, sink, 0xffffffffu, false, probe);
 }
 
 // ------------------------------------------------------------------ k_me_walk
@@ -882,10 +895,32 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
     int jend;
     // more than FER_ST2_CAP candidates make the partition "crowded" (below): the count itself is not needed then, and
     // the step the stop test would fire in is the current one (the count is already past 128)
+    // A partition inside a flat area would read tens of thousands of records of the area's bucket before it has seen the
+    // 385 candidates that make it crowded.  Instead the 25 x 25 positions around the block are looked up in the feature
+    // map: those of the bucket's modal class (FerDev.bmodal) that pass the walk's tests ARE candidates of that slice.
+    const uint16_t *F0p = d.feat0 + (size_t)s * 6 * d.ysz;
+    auto flat_probe = [&](int a) -> int {
+        if (d.zero_cnt[s] != 0) return 0;
+        const uint32_t *bmq = d.bmodal + ((size_t)s * 16384 + a) * 4;
+        const uint32_t m1 = bmq[0], m2 = bmq[1];
+        if (bmq[2] > FER_OUTL) return 0;  // no modal class
+        const uint32_t e12 = pk_abs16(pk_sub16(m1, sp.s12));
+        if ((pk_sub16(e12, 0x00640064u) & 0x80008000u) != 0x80008000u) return 0;  // the class fails the half-sum test
+        int n = 0;
+        for (int k0 = 0; k0 < 625; k0 += 64) {
+            const int k = k0 + lane;
+            const int px = sx + k % 25 - 12, py = sy + k / 25 - 12;
+            const bool in = k < 625 && px >= 0 && px < d.W && py >= 0 && py < d.H;
+            const uint32_t *rec = (const uint32_t *)(F0p + ((size_t)iclamp(py, 0, d.H - 1) * d.W + iclamp(px, 0, d.W - 1)) * 6);
+            const uint32_t ra = rec[0], rb = rec[1], rc = rec[2];
+            n += __popcll(__ballot(in && (int)(ra & 0xffffu) == a && ((ra >> 16) | (rb << 16)) == m1 && ((rb >> 16) | (rc << 16)) == m2));
+        }
+        return n;
+    };
     const int tren = walk_buckets(d, s, su, sp, sx, sy, lane, tbl, FER_ST2_CAP, jend, [&](bool ok, int rank, int rel, int D, uint32_t) {
         if (ok && rank < FER_ST2_CAP) out[rank] = make_int2(rel, D);
         return false;
-    });
+    }, flat_probe);
     if (tren > FER_ST2_CAP && d.zero_cnt[s] == 0) {
         // A crowded partition (flat areas: thousands of positions share a feature vector).  k_me_resolve will not go
         // through the candidates again; it looks for the winners around the predictor (resolve_crowded), for which it
