@@ -77,6 +77,7 @@ struct FerDev {
     // order; 0xffffffff = none); boutl[S][FER_OSLOTS][FER_OUTL] = the sorted-array indices of those records (any order).  With at most FER_OUTL outliers the class is bounded EXACTLY by its one
     // feature distance and the outliers are listed as candidates of their own (k_me_walk, resolve_crowded).
     uint32_t *bmodal, *boutl;
+    int *nbig;           // [S] big buckets of the stream's reference picture (0 = nothing to do for the two kernels above)
     int *zero_cnt;       // [S] positions of the reference picture whose 8x8 sum is 0 (see "bucket 0" in k_sort_finish)
     // per-MB side information (a20)
     int *mb_type;        // [S][nmb]

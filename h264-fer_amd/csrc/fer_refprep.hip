@@ -527,6 +527,7 @@ __global__ __launch_bounds__(256) void k_sort_index(FerDev d, const uint16_t *sk
 __global__ __launch_bounds__(256) void k_bucket_ranges(FerDev d, const uint16_t *skey)
 {
     const int s = blockIdx.y;
+    if (d.nbig[s] == 0) return;  // (k_bucket_slots: also 0 for streams that are not P pictures or carry sum-0 positions)
     if (d.hdr[s * 4 + 3] != 0 || d.zero_cnt[s] != 0) return;  // (a stream with sum-0 positions: its crowded partitions take the exact slow path)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = d.W * d.H;
@@ -568,6 +569,7 @@ __global__ __launch_bounds__(256) void k_bucket_slots(FerDev d)
 {
     __shared__ int part[256];
     const int s = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) d.nbig[s] = 0;
     if (d.hdr[s * 4 + 3] != 0 || d.zero_cnt[s] != 0) return;
     const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * d.kt;
     int cnt = 0;
@@ -581,6 +583,7 @@ __global__ __launch_bounds__(256) void k_bucket_slots(FerDev d)
         __syncthreads();
     }
     int slot = part[tid] - cnt;
+    if (tid == 255) d.nbig[s] = part[255];
     for (int a = tid * 64; a < tid * 64 + 64; a++) {
         const bool big = kol2[(size_t)(a + 1) * d.kt] - kol2[(size_t)a * d.kt] > FER_BRANGE_MIN;
         d.bmodal[((size_t)s * 16384 + a) * 4 + 3] = big && slot < FER_OSLOTS ? (uint32_t)slot : 0xffffffffu;
@@ -594,6 +597,7 @@ __global__ __launch_bounds__(256) void k_bucket_slots(FerDev d)
 __global__ __launch_bounds__(256) void k_bucket_modal(FerDev d, const uint16_t *skey)
 {
     const int s = blockIdx.y;
+    if (d.nbig[s] == 0) return;
     if (d.hdr[s * 4 + 3] != 0 || d.zero_cnt[s] != 0) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = d.W * d.H;
@@ -728,10 +732,12 @@ void fer_launch_sort_finish(const FerDev &d, FerSortTmp &t, hipStream_t st)
 {
     const int n = d.W * d.H;
     hipMemsetAsync(d.brange, 0, (size_t)d.S * 16384 * 8 * sizeof(uint32_t), st);
-    hipLaunchKernelGGL(k_sort_index, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
-    hipLaunchKernelGGL(k_bucket_ranges, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
     hipMemsetAsync(d.bmodal, 0, (size_t)d.S * 16384 * 4 * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_sort_index, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
+    // big buckets (flat areas): numbered, then their feature ranges, modal classes and outlier lists; streams without any
+    // leave both per-record kernels at once
     hipLaunchKernelGGL(k_bucket_slots, dim3(d.S), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_bucket_ranges, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
     hipLaunchKernelGGL(k_bucket_modal, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
     hipLaunchKernelGGL(k_sort_quirk, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.rec_tmp);
 }
