@@ -233,7 +233,8 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     rc |= dalloc(c, &d.kol2, decode_only ? (size_t)1 : (size_t)(nbins));
     rc |= dalloc(c, &d.brange, decode_only ? (size_t)1 : (size_t)S * 16384 * 8);
     rc |= dalloc(c, &d.bmodal, decode_only ? (size_t)1 : (size_t)S * 16384 * 4);
-    rc |= dalloc(c, &d.boutl, decode_only ? (size_t)1 : (size_t)S * FER_OSLOTS * FER_OUTL);
+    d.nlists = W * H / FER_BRANGE_MIN + 1;
+    rc |= dalloc(c, &d.boutl, decode_only ? (size_t)1 : (size_t)S * d.nlists * FER_OUTL);
     rc |= dalloc(c, &d.nbig, (size_t)S);
     rc |= dalloc(c, &d.zero_cnt, (size_t)S);
     size_t nm = (size_t)d.nmb * S;

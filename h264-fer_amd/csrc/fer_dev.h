@@ -31,7 +31,6 @@
 #define FER_BIGS 3            // big bucket slices of a crowded partition that are described by class (more = the general bound)
 #define FER_P2_CAP 320        // listed candidates of a crowded partition (slots 64 .. 383 of its stage-2 list)
 #define FER_OUTL 512          // outliers of a big bucket that are listed (more = the bucket has no modal class)
-#define FER_OSLOTS 256        // big buckets of a stream that get an outlier list
 #define FER_BRANGE_MIN 1024  // buckets with more positions than this get feature ranges (FerDev.brange)
 #define FER_ST2_CAP 384  // stage-2 candidates kept per 8x8 partition
 #define FER_BIG_SLICE 1024  // records of one bucket inside a partition's column range beyond which k_me_walk bounds instead of reading
@@ -73,11 +72,12 @@ struct FerDev {
     uint32_t *brange;
     // A bucket of more than FER_BRANGE_MIN positions is usually ONE flat area plus a few stray positions of the same
     // sum: bmodal[S][16384][4] = the two feature dwords of the record in the middle of the bucket (its "modal class"),
-    // the number of records that differ from it, the bucket's outlier list (the big buckets are numbered in bucket
-    // order; 0xffffffff = none); boutl[S][FER_OSLOTS][FER_OUTL] = the sorted-array indices of those records (any order).  With at most FER_OUTL outliers the class is bounded EXACTLY by its one
+    // the number of records that differ from it, unused; boutl[S][nlists][FER_OUTL] = the sorted-array indices of those
+    // records (any order), list number = the bucket's first place in the stream's sorted order / FER_BRANGE_MIN.  With at most FER_OUTL outliers the class is bounded EXACTLY by its one
     // feature distance and the outliers are listed as candidates of their own (k_me_walk, resolve_crowded).
     uint32_t *bmodal, *boutl;
-    int *nbig;           // [S] big buckets of the stream's reference picture (0 = nothing to do for the two kernels above)
+    int *nbig;           // [S] == serial: the stream's reference picture has big buckets (set by k_sort_index)
+    int nlists;          // outlier lists per stream = W*H / FER_BRANGE_MIN + 1
     int *zero_cnt;       // [S] positions of the reference picture whose 8x8 sum is 0 (see "bucket 0" in k_sort_finish)
     // per-MB side information (a20)
     int *mb_type;        // [S][nmb]

@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(64, 8) void k_me_walk(FerDev d)
                     bigD[q] = members && DM > 0 ? (int)DM : 0x7fffffff;
                     dminN = min(dminN, bigD[q]);
                     // the outliers, 64 to a batch
-                    const uint32_t *ol = d.boutl + ((size_t)s * FER_OSLOTS + bmq[3]) * FER_OUTL;
+                    const uint32_t *ol = d.boutl + ((size_t)s * d.nlists + (d.kol2[((size_t)s * 16384 + bigA[q]) * d.kt] - g0_) / FER_BRANGE_MIN) * FER_OUTL;
                     for (uint32_t o0 = 0; o0 < nout; o0 += 64) {
                         const bool lv = o0 + (uint32_t)lane < nout;
                         const uint32_t idx = lv ? ol[o0 + lane] : g0_;

@@ -496,6 +496,16 @@ __global__ __launch_bounds__(256) void k_sort_index(FerDev d, const uint16_t *sk
         gap_lo = prev + 1;
         gap_hi = bin + 1;
         gval = (uint32_t)(g0 + i);
+        // the first record of a bucket clears what the big-bucket kernels accumulate for it (ranges, modal class), and a
+        // record whose key is still the same 1024 places on says "this stream has big buckets" for this picture
+        const int key = (int)skey[g0 + i];
+        if (i == 0 || (int)skey[g0 + i - 1] != key) {
+            uint4 *br = (uint4 *)(d.brange + ((size_t)s * 16384 + key) * 8);
+            br[0] = make_uint4(0, 0, 0, 0);
+            br[1] = make_uint4(0, 0, 0, 0);
+            *(uint4 *)(d.bmodal + ((size_t)s * 16384 + key) * 4) = make_uint4(0, 0, 0, 0);
+        }
+        if (i + FER_BRANGE_MIN < n && (int)skey[g0 + i + FER_BRANGE_MIN] == key) d.nbig[s] = d.serial;
     }
     // the last record also closes the index: every bin after its own, and the end marker, start at the segment end
     const bool tail = i == n - 1;
@@ -519,86 +529,20 @@ __global__ __launch_bounds__(256) void k_sort_index(FerDev d, const uint16_t *sk
     }
 }
 
-// Ranges of the other four sums over the positions of a bucket, for the LARGE buckets only (more than
-// FER_BRANGE_MIN positions: flat areas).  k_me_walk bounds the feature distance of a crowded partition's candidates
-// with them; a bucket without ranges is simply unbounded there.  One thread per sorted record: the bucket's size comes
-// from the index, a wavefront usually sits inside one bucket and folds its 64 records into one set of atomics, which
-// it skips when the range already covers them.
-__global__ __launch_bounds__(256) void k_bucket_ranges(FerDev d, const uint16_t *skey)
+// The big buckets (more than FER_BRANGE_MIN positions: flat areas), one thread per sorted record, for the streams k_sort_index
+// found any in:
+//  * brange: the ranges of the other four sums over the bucket's positions (k_me_walk bounds the feature distance of a crowded
+//    partition's candidates with them where no better description applies).  A wavefront usually sits inside one bucket and
+//    folds its 64 records into one set of atomics, which it skips when the range already covers them.
+//  * bmodal / boutl: the bucket's modal class = the feature dwords of its middle record, the number of records that differ
+//    from it, and their sorted-array indices (list number = the bucket's first place / FER_BRANGE_MIN: unique, since every
+//    big bucket has more places than that).  A wavefront counts its outliers with one atomic per bucket it touches and stops
+//    adding once the bucket is known to have too many.
+__global__ __launch_bounds__(256) void k_bucket_classes(FerDev d, const uint16_t *skey)
 {
     const int s = blockIdx.y;
-    if (d.nbig[s] == 0) return;  // (k_bucket_slots: also 0 for streams that are not P pictures or carry sum-0 positions)
+    if (d.nbig[s] != d.serial) return;  // (k_sort_index of this picture)
     if (d.hdr[s * 4 + 3] != 0 || d.zero_cnt[s] != 0) return;  // (a stream with sum-0 positions: its crowded partitions take the exact slow path)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = d.W * d.H;
-    const size_t g0 = (size_t)s * n;
-    const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * d.kt;
-    const bool in = i < n;
-    const int key = in ? (int)skey[g0 + i] : -1;
-    const bool on = in && kol2[(size_t)(key + 1) * d.kt] - kol2[(size_t)key * d.kt] > FER_BRANGE_MIN;
-    if (!__any(on)) return;
-    uint32_t v[4] = {0, 0, 0, 0};
-    if (on) {
-        const uint32_t *r = d.sort_rec + (g0 + i) * 3;
-        const uint32_t r1 = r[1], r2 = r[2];
-        v[0] = r1 & 0xffffu;
-        v[1] = r1 >> 16;
-        v[2] = r2 & 0xffffu;
-        v[3] = r2 >> 16;
-    }
-    unsigned long long todo = __ballot(on);
-    while (todo) {
-        const int kcur = __builtin_amdgcn_readlane(key, __ffsll((long long)todo) - 1);
-        const bool mine = on && key == kcur;
-        todo &= ~__ballot(mine);
-        uint32_t *br = d.brange + ((size_t)s * 16384 + (size_t)kcur) * 8;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int hi = wave_max(mine ? (int)v[k] : 0), lo = wave_max(mine ? 65535 - (int)v[k] : 0);
-            if ((threadIdx.x & 63) == 0) {
-                if ((uint32_t)hi > __hip_atomic_load(&br[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&br[k], (uint32_t)hi);
-                if ((uint32_t)lo > __hip_atomic_load(&br[4 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&br[4 + k], (uint32_t)lo);
-            }
-        }
-    }
-}
-
-// Numbers the big buckets of a stream (more than FER_BRANGE_MIN positions) in bucket order: the first FER_OSLOTS of them
-// get an outlier list.  One workgroup per stream, 64 buckets per thread.
-__global__ __launch_bounds__(256) void k_bucket_slots(FerDev d)
-{
-    __shared__ int part[256];
-    const int s = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) d.nbig[s] = 0;
-    if (d.hdr[s * 4 + 3] != 0 || d.zero_cnt[s] != 0) return;
-    const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * d.kt;
-    int cnt = 0;
-    for (int a = tid * 64; a < tid * 64 + 64; a++) cnt += kol2[(size_t)(a + 1) * d.kt] - kol2[(size_t)a * d.kt] > FER_BRANGE_MIN;
-    part[tid] = cnt;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        int v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int slot = part[tid] - cnt;
-    if (tid == 255) d.nbig[s] = part[255];
-    for (int a = tid * 64; a < tid * 64 + 64; a++) {
-        const bool big = kol2[(size_t)(a + 1) * d.kt] - kol2[(size_t)a * d.kt] > FER_BRANGE_MIN;
-        d.bmodal[((size_t)s * 16384 + a) * 4 + 3] = big && slot < FER_OSLOTS ? (uint32_t)slot : 0xffffffffu;
-        slot += big;
-    }
-}
-
-// Modal class and outliers of the big buckets (FerDev.bmodal / boutl): one thread per sorted record.  A wavefront usually
-// sits inside one bucket; it counts its outliers with one atomic per bucket it touches and stops adding once the
-// bucket is known to have too many.
-__global__ __launch_bounds__(256) void k_bucket_modal(FerDev d, const uint16_t *skey)
-{
-    const int s = blockIdx.y;
-    if (d.nbig[s] == 0) return;
-    if (d.hdr[s * 4 + 3] != 0 || d.zero_cnt[s] != 0) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = d.W * d.H;
     const size_t g0 = (size_t)s * n;
@@ -612,37 +556,49 @@ __global__ __launch_bounds__(256) void k_bucket_modal(FerDev d, const uint16_t *
     }
     const bool on = in && be - bs > FER_BRANGE_MIN;
     if (!__any(on)) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t v[4] = {0, 0, 0, 0};
     bool outl = false;
     if (on) {
         const uint32_t *m = d.sort_rec + (size_t)(bs + (be - bs) / 2) * 3, *r = d.sort_rec + (g0 + i) * 3;
-        const uint32_t m1 = m[1], m2 = m[2];
-        outl = r[1] != m1 || r[2] != m2;
+        const uint32_t r1 = r[1], r2 = r[2], m1 = m[1], m2 = m[2];
+        v[0] = r1 & 0xffffu;
+        v[1] = r1 >> 16;
+        v[2] = r2 & 0xffffu;
+        v[3] = r2 >> 16;
+        outl = r1 != m1 || r2 != m2;
         if (g0 + i == bs) {
             uint32_t *bm = d.bmodal + ((size_t)s * 16384 + key) * 4;
             bm[0] = m1;
             bm[1] = m2;
         }
     }
-    unsigned long long todo = __ballot(outl);
-    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(on);
     while (todo) {
-        const int kcur = __builtin_amdgcn_readlane(key, __ffsll((long long)todo) - 1);
-        const bool mine = outl && key == kcur;
-        const unsigned long long mm = __ballot(mine);
-        todo &= ~mm;
-        uint32_t *bm = d.bmodal + ((size_t)s * 16384 + kcur) * 4;
-        const uint32_t slot = bm[3];  // (written by k_bucket_slots)
-        uint32_t base = FER_OUTL + 1;
-        if (lane == 0) {
-            if (slot == 0xffffffffu)
-                bm[2] = FER_OUTL + 1;  // no list for this bucket: it counts as one without a modal class
-            else if (__hip_atomic_load(bm + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= FER_OUTL)
-                base = atomicAdd(bm + 2, (uint32_t)__popcll(mm));
+        const int src = __ffsll((long long)todo) - 1;
+        const int kcur = __builtin_amdgcn_readlane(key, src);
+        const bool mine = on && key == kcur;
+        todo &= ~__ballot(mine);
+        uint32_t *br = d.brange + ((size_t)s * 16384 + (size_t)kcur) * 8;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int hi = wave_max(mine ? (int)v[k] : 0), lo = wave_max(mine ? 65535 - (int)v[k] : 0);
+            if (lane == 0) {
+                if ((uint32_t)hi > __hip_atomic_load(&br[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&br[k], (uint32_t)hi);
+                if ((uint32_t)lo > __hip_atomic_load(&br[4 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&br[4 + k], (uint32_t)lo);
+            }
         }
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (mine && slot != 0xffffffffu) {
-            const uint32_t k = base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-            if (k < FER_OUTL) d.boutl[((size_t)s * FER_OSLOTS + slot) * FER_OUTL + k] = (uint32_t)(g0 + i);
+        const unsigned long long mo = __ballot(mine && outl);
+        if (mo) {
+            uint32_t *bm = d.bmodal + ((size_t)s * 16384 + kcur) * 4;
+            const uint32_t list = ((uint32_t)__builtin_amdgcn_readlane((int)bs, src) - (uint32_t)g0) / FER_BRANGE_MIN;
+            uint32_t base = FER_OUTL + 1;
+            if (lane == 0 && __hip_atomic_load(bm + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= FER_OUTL) base = atomicAdd(bm + 2, (uint32_t)__popcll(mo));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (mine && outl) {
+                const uint32_t k = base + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull));
+                if (k < FER_OUTL) d.boutl[((size_t)s * d.nlists + list) * FER_OUTL + k] = (uint32_t)(g0 + i);
+            }
         }
     }
 }
@@ -731,14 +687,8 @@ void fer_launch_sort_radix(const FerDev &d, FerSortTmp &t, hipStream_t st)
 void fer_launch_sort_finish(const FerDev &d, FerSortTmp &t, hipStream_t st)
 {
     const int n = d.W * d.H;
-    hipMemsetAsync(d.brange, 0, (size_t)d.S * 16384 * 8 * sizeof(uint32_t), st);
-    hipMemsetAsync(d.bmodal, 0, (size_t)d.S * 16384 * 4 * sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_sort_index, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
-    // big buckets (flat areas): numbered, then their feature ranges, modal classes and outlier lists; streams without any
-    // leave both per-record kernels at once
-    hipLaunchKernelGGL(k_bucket_slots, dim3(d.S), dim3(256), 0, st, d);
-    hipLaunchKernelGGL(k_bucket_ranges, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
-    hipLaunchKernelGGL(k_bucket_modal, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
+    hipLaunchKernelGGL(k_bucket_classes, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
     hipLaunchKernelGGL(k_sort_quirk, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.rec_tmp);
 }
 
