@@ -52,7 +52,7 @@ KERNELS = {
     "interp": ("k_interp", 256 + 16 * 256, "hbm", "P"),
     "sort_keys": ("k_feat0", 256 + 256 * (12 + 16 + 2), "hbm", "P"),
     "sort": ("k_rs_hist+k_rs_scan+k_rs_scatter (two radix passes)", 256 * (2 + 1 + 2 + 16 + 16 + 1 + 1 + 16 + 12 + 4 + 2), "hbm", "P"),
-    "sort_finish": ("k_sort_index+k_sort_quirk", 256 * 6 + 1956, "hbm", "P"),
+    "sort_finish": ("k_sort_index+k_bucket_classes+k_sort_quirk", 256 * 6 + 1956, "hbm", "P"),
     "me_pre": ("k_me_pre", ME_BYTES_PER_MB, "valu", "P"),
     "me_walk": ("k_me_walk", ME_BYTES_PER_MB, "valu", "P"),
     "me_resolve": ("k_me_resolve", ME_BYTES_PER_MB, "valu", "P"),
