@@ -328,9 +328,11 @@ struct LocalGeo {
     static constexpr int N1 = 2 * R1 + 1, PW = 2 * R1 + 8, NC = N1 * N1 * 16, NB = (NC + 63) / 64;
     static constexpr int HTAB = 8 * PW * N1 * 2;
 };
+// half_lo .. half_hi: which groups of 8 planes this call computes (k_me_resolve splits them over its two wavefronts, each
+// with its own htab; the caller orders the shared mtab).
 template <int R1>
 __device__ __forceinline__ void local_metrics(const IPlanes &ip, int W, int H, int px0, int py0, const SuPk &sp, int lane,
-                                              uint32_t *htab, int *mtab)
+                                              uint32_t *htab, int *mtab, int half_lo = 0, int half_hi = 2)
 {
     using G = LocalGeo<R1>;
     constexpr int N1 = G::N1, PW = G::PW;
@@ -344,7 +346,7 @@ __device__ __forceinline__ void local_metrics(const IPlanes &ip, int W, int H, i
     }
     const uint32_t sh = (uint32_t)(px0 & 3);
     const uint8_t *pbase = ip.base + (ptrdiff_t)py0 * ip.pitch + (px0 & ~3);
-    for (int half = 0; half < 2; half++) {
+    for (int half = half_lo; half < half_hi; half++) {
         // ---- horizontal sums: row tasks (plane, row)
 #pragma unroll
         for (int t0 = 0; t0 < 8 * PW; t0 += 64) {
@@ -396,8 +398,10 @@ __device__ __forceinline__ void local_metrics(const IPlanes &ip, int W, int H, i
         }
         WAVE_LDS_SYNC();
     }
+    if (half_lo == 0) {
 #pragma unroll
-    for (int c = G::NC + lane; c < G::NB * 64; c += 64) mtab[c] = -1;  // the padding of the last batch
+        for (int c = G::NC + lane; c < G::NB * 64; c += 64) mtab[c] = -1;  // the padding of the last batch
+    }
     WAVE_LDS_SYNC();
 }
 
@@ -1224,9 +1228,37 @@ __device__ __forceinline__ void wave_best(int best, int bestxy, int &wkey, int &
 }
 
 // role 0: P_Skip test (partition 0) and stage 1.  Returns skip; otherwise the best stage-1 (key, vector).
+// The on-chip features of stage 1's local search are built by BOTH wavefronts of the workgroup, 8 planes each (their own
+// row-sum tables, one table of metrics): wavefront 0 after the P_Skip test (resolve_stage1_front), wavefront 1 before its
+// stages 2 and 3 (resolve_local_back); a workgroup barrier later wavefront 0 selects and refines (resolve_stage1_rest).
+#define RES_HTAB LocalGeo<2>::HTAB
 template <int WIN>
-__device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
-                                               int *sel_lds, uint32_t *loc_lds, int &skipw, int &wkey, int &wxy)
+__device__ __forceinline__ void resolve_local_half(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
+                                                   uint32_t *loc_lds, int half)
+{
+    if (FER_DBGF(d, 16)) return;
+    if (WIN == 32 || WIN == 16) {
+        constexpr int RR = (WIN ? WIN : 32) / 16;
+        const int window = WIN ? WIN : d.window;
+        const int r1 = window / 16;
+        const SuPk sp = su_pack(P.su);
+        int mvpx, mvpy;
+        predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
+        local_metrics<RR>(ip_stream(d, s), d.W, d.H, gx * 8 + (mvpx >> 2) - r1, gy * 8 + (mvpy >> 2) - r1, sp, lane, loc_lds + half * RES_HTAB,
+                          (int *)loc_lds + 2 * RES_HTAB, half, half + 1);
+    }
+}
+template <int WIN>
+__device__ __forceinline__ void resolve_local_back(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
+                                                   uint32_t *loc_lds)
+{
+    resolve_local_half<WIN>(d, s, gx, gy, lane, P, N, loc_lds, 1);
+}
+
+// role 0, before the barrier: P_Skip test (partition 0) -> true = skip; otherwise the first half of the local features
+template <int WIN>
+__device__ __forceinline__ bool resolve_stage1_front(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
+                                                     uint32_t *loc_lds, int &skipw)
 {
     const int window = WIN ? WIN : d.window;
     const int mbx = gx >> 1, mby = gy >> 1, part = (gy & 1) * 2 + (gx & 1);
@@ -1238,8 +1270,6 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
     const IPlanes ip = ip_stream(d, s);
     const int xp = mbx << 4, yp = mby << 4;
     const int sx = gx * 8, sy = gy * 8;
-    wkey = 0x7fffffff;
-    wxy = 0;
     skipw = 0;
 
     if (part == 0) {
@@ -1279,17 +1309,27 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
             return true;
         }
     }
+    resolve_local_half<WIN>(d, s, gx, gy, lane, P, N, loc_lds, 0);
+    return false;
+}
 
+// role 0, after the barrier: stage 1 proper -> the best (key, vector)
+template <int WIN>
+__device__ __forceinline__ void resolve_stage1_rest(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
+                                                    int *sel_lds, uint32_t *loc_lds, int &wkey, int &wxy)
+{
+    const int window = WIN ? WIN : d.window;
+    const int W = d.W, H = d.H;
+    const IPlanes ip = ip_stream(d, s);
+    const int sx = gx * 8, sy = gy * 8;
+    wkey = 0x7fffffff;
+    wxy = 0;
     // ---- stage 1: +-W/16 around the predictor, all 16 fractional planes (K = 17)
     const SuPk sp = su_pack(P.su);
     int mvpx, mvpy;
     predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
     const int genx = mvpx >> 2, geny = mvpy >> 2;
-    if (FER_DBGF(d, 16)) {  // (probe: the chain without stage 1)
-        wkey = 0x7fffffff;
-        wxy = 0;
-        return false;
-    }
+    if (FER_DBGF(d, 16)) return;  // (probe: the chain without stage 1)
     WList L1;
     L1.m = INF_M;
     L1.xy = 0;
@@ -1302,10 +1342,9 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
     if (WIN == 32 || WIN == 16) {
         constexpr int RR = (WIN ? WIN : 32) / 16;
         constexpr int NB1 = LocalGeo<RR>::NB;
-        local_metrics<RR>(ip, W, H, sx + genx - r1, sy + geny - r1, sp, lane, loc_lds, (int *)loc_lds + LocalGeo<RR>::HTAB);
         int m[NB1];
 #pragma unroll
-        for (int u = 0; u < NB1; u++) m[u] = FER_DBGF(d, 16) ? -1 : ((const int *)loc_lds)[LocalGeo<RR>::HTAB + u * 64 + lane];
+        for (int u = 0; u < NB1; u++) m[u] = ((const int *)loc_lds)[2 * RES_HTAB + u * 64 + lane];
         select_topk<NB1>(m, 17, lane, sel_lds, L1, raw1, fin1);
     } else {
         for (int base = 0; base < tot1; base += 64) {
@@ -1326,7 +1365,6 @@ __device__ __forceinline__ bool resolve_stage1(const FerDev &d, int s, int gx, i
     int b1, b1xy;
     sad_keys<17>(L1, cnt1, lane, ip, W, H, sx, sy, P.sb, mvpx, mvpy, b1, b1xy);
     wave_best(b1, b1xy, wkey, wxy);
-    return false;
 }
 
 // ---- stage 2 of a crowded partition: the winners are looked for AROUND THE PREDICTOR ----
@@ -1540,7 +1578,7 @@ template <int WIN>
 __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
 {
     __shared__ __attribute__((aligned(16))) int sel_all[2][256];
-    __shared__ __attribute__((aligned(16))) uint32_t loc_lds[LocalGeo<2>::HTAB + LocalGeo<2>::NB * 64];  // local search of wavefront 0
+    __shared__ __attribute__((aligned(16))) uint32_t loc_lds[2 * LocalGeo<2>::HTAB + LocalGeo<2>::NB * 64];  // stage 1's local search: row sums of either wavefront, metrics
     __shared__ int xch[8];
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1650,8 +1688,10 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
             const long long tst = wall_clock64();
 #endif
             if (role == 0) {
-                int skipw, k1, xy1;
-                bool sk = resolve_stage1<WIN>(d, s, gx, gy, ln, cur, N, sel_lds, loc_lds, skipw, k1, xy1);
+                int skipw, k1 = 0x7fffffff, xy1 = 0;
+                const bool sk = resolve_stage1_front<WIN>(d, s, gx, gy, ln, cur, N, loc_lds, skipw);
+                __syncthreads();  // the other half of the local features is in place
+                if (!sk) resolve_stage1_rest<WIN>(d, s, gx, gy, ln, cur, N, sel_lds, loc_lds, k1, xy1);
 #ifdef FER_PROBE
                 if (FER_DBGF(d, 128) && s == 0 && lane == 0)  // the slowest stage-1 call of the picture and where it was
                     atomicMax((unsigned long long *)&d.timing[40], ((unsigned long long)(wall_clock64() - tst) << 24) | ((unsigned long long)gx << 12) | (unsigned long long)gy);
@@ -1699,6 +1739,8 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
                 if (part == 0) skip = sk;
             } else {
                 int k2, xy2, k3, xy3;
+                resolve_local_back<WIN>(d, s, gx, gy, ln, cur, N, loc_lds);
+                __syncthreads();
                 resolve_stage23<WIN>(d, s, gx, gy, ln, cur, N, sel_lds, k2, xy2, k3, xy3);
 #ifdef FER_PROBE
                 if (FER_DBGF(d, 128) && s == 0 && lane == 0) {
