@@ -133,3 +133,71 @@ extern "C" void RBSP_decode(NALunit nal_unit)
         writeToY4M();
     }
 }
+
+// ---- block-level entry points under the reference's names (F/quantizationTransform.h, F/scaleTransform.h): one block per
+// call through the batched device entry points of ferhip.h
+static void legacy_block(const char *name, int rc)
+{
+    if (rc) fprintf(stderr, "%s: device call failed (%d)\n", name, rc);
+}
+extern "C" void forwardResidual(int qP, int c[4][4], int r[4][4], unsigned char Intra, unsigned char Intra16x16OrChroma)
+{
+    (void)Intra;  // unused by the reference as well (F/quantizationTransform.cpp:183-223)
+    int32_t o[16];
+    int rc = ferhip_forward_residual(qP, &c[0][0], o, Intra16x16OrChroma ? 1 : 0, 1);
+    legacy_block("forwardResidual", rc);
+    if (!rc) memcpy(&r[0][0], o, sizeof o);
+}
+extern "C" void transformScan(int c[4][4], int list[16], unsigned char Intra16x16AC)
+{
+    int32_t o[16];
+    int rc = ferhip_transform_scan(&c[0][0], o, Intra16x16AC ? 1 : 0, 1);
+    legacy_block("transformScan", rc);
+    if (!rc) memcpy(list, o, sizeof(int32_t) * (Intra16x16AC ? 15 : 16));
+}
+extern "C" void forwardDCLumaIntra(int qP, int dcY[4][4], int c[4][4])
+{
+    int32_t o[16];
+    int rc = ferhip_forward_dc_luma_intra(qP, &dcY[0][0], o, 1);
+    legacy_block("forwardDCLumaIntra", rc);
+    if (!rc) memcpy(&c[0][0], o, sizeof o);
+}
+extern "C" void forwardDCChroma(int qP, int dcC[2][2], int c[2][2], unsigned char Intra)
+{
+    (void)Intra;
+    int32_t i[16] = {dcC[0][0], dcC[0][1], dcC[1][0], dcC[1][1]}, o[16];
+    int rc = ferhip_forward_dc_chroma(qP, i, o, 1);
+    legacy_block("forwardDCChroma", rc);
+    if (!rc) memcpy(&c[0][0], o, sizeof(int32_t) * 4);
+}
+extern "C" void transformInverseScan(int list[16], int c[4][4])
+{
+    int32_t o[16];
+    int rc = ferhip_transform_inverse_scan(list, o, 1);
+    legacy_block("transformInverseScan", rc);
+    if (!rc) memcpy(&c[0][0], o, sizeof o);
+}
+extern "C" void inverseResidual(int bitDepth, int qP, int c[4][4], int r[4][4], unsigned char intra16x16OrChroma)
+{
+    (void)bitDepth;  // 8 everywhere in the reference
+    int32_t o[16];
+    int rc = ferhip_inverse_residual(qP, &c[0][0], o, intra16x16OrChroma ? 1 : 0, 1);
+    legacy_block("inverseResidual", rc);
+    if (!rc) memcpy(&r[0][0], o, sizeof o);
+}
+extern "C" void InverseDCLumaIntra(int bitDepth, int qP, int c[4][4], int dcY[4][4])
+{
+    (void)bitDepth;
+    int32_t o[16];
+    int rc = ferhip_inverse_dc_luma_intra(qP, &c[0][0], o, 1);
+    legacy_block("InverseDCLumaIntra", rc);
+    if (!rc) memcpy(&dcY[0][0], o, sizeof o);
+}
+extern "C" void InverseDCChroma(int bitDepth, int qP, int c[2][2], int dcC[2][2])
+{
+    (void)bitDepth;
+    int32_t i[16] = {c[0][0], c[0][1], c[1][0], c[1][1]}, o[16];
+    int rc = ferhip_inverse_dc_chroma(qP, i, o, 1);
+    legacy_block("InverseDCChroma", rc);
+    if (!rc) memcpy(&dcC[0][0], o, sizeof(int32_t) * 4);
+}

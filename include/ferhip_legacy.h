@@ -16,6 +16,8 @@
  *   int brojTipova[5], vrijeme                                                               F/h264_globals.h:166-167
  *   void RBSP_decode(NALunit nal_unit)               void RBSP_decode(NALunit nal_unit)      F/rbsp_decoding.h:3
  *   LoadY4MHeader / ReadFromY4M / writeToY4M / writeToYUV, FILE *yuvinput, *yuvoutput        F/fileIO.h
+ *   forwardResidual, transformScan, forwardDCLumaIntra, forwardDCChroma                      F/quantizationTransform.h
+ *   transformInverseScan, inverseResidual, InverseDCLumaIntra, InverseDCChroma               F/scaleTransform.h
  *
  * Contract kept from F/rbsp_encoding.cpp:119-326: nal_unit_type 7 / 8 write SPS / PPS (the SPS
  * call also sizes the encoder from frame.Lwidth x frame.Lheight); 5 / 1 encode the picture in
@@ -64,6 +66,20 @@ void LoadY4MHeader(void);
 int ReadFromY4M(void);
 void writeToY4M(void);
 void writeToYUV(void);
+
+/* The block-level entry points of F/quantizationTransform.h and F/scaleTransform.h under their own names (the unit-parity
+ * surface of SURVEY 8b): one block per call through the same device functions the encode / decode kernels use -- a seam
+ * for the maintainer's unit tests, not a fast path (the batched forms are ferhip_forward_residual ... in ferhip.h).
+ * `unsigned char` stands for the reference's bool.  On a device error the output is left unchanged and a message goes
+ * to stderr (the reference returns void). */
+void forwardResidual(int qP, int c[4][4], int r[4][4], unsigned char Intra, unsigned char Intra16x16OrChroma); /* F/quantizationTransform.cpp:284 */
+void transformScan(int c[4][4], int list[16], unsigned char Intra16x16AC);                                     /* :310 */
+void forwardDCLumaIntra(int qP, int dcY[4][4], int c[4][4]);                                                   /* :293 */
+void forwardDCChroma(int qP, int dcC[2][2], int c[2][2], unsigned char Intra);                                 /* :302 */
+void transformInverseScan(int list[16], int c[4][4]);                                                          /* F/scaleTransform.cpp:454 */
+void inverseResidual(int bitDepth, int qP, int c[4][4], int r[4][4], unsigned char intra16x16OrChroma);        /* F/scaleTransform.h */
+void InverseDCLumaIntra(int bitDepth, int qP, int c[4][4], int dcY[4][4]);
+void InverseDCChroma(int bitDepth, int qP, int c[2][2], int dcC[2][2]);
 
 #ifdef __cplusplus
 }

@@ -117,6 +117,57 @@ def test_dc_transform_and_scan_kats(pkg, fo):
     assert np.array_equal(block_op("transform_inverse_scan", block_op("transform_scan", lv)), lv)
 
 
+def test_block_entry_points_under_the_reference_names(pkg, fo):
+    """The unit-parity surface of SURVEY 8b: forwardResidual, transformScan, forwardDCLumaIntra, forwardDCChroma
+    (F/quantizationTransform.h), transformInverseScan, inverseResidual, InverseDCLumaIntra, InverseDCChroma
+    (F/scaleTransform.h) exported by libferhip under their own names with the reference's argument lists, one block per
+    call, against the oracle."""
+    import ctypes as C
+    lib = pkg.load_library()
+    rng = np.random.default_rng(5)
+    I4, I16, I2 = (C.c_int * 4) * 4, C.c_int * 16, (C.c_int * 2) * 2
+
+    def arr(t, v):
+        a = t()
+        C.memmove(a, np.ascontiguousarray(v, np.int32).ctypes.data, C.sizeof(a))
+        return a
+
+    def out(a, n):
+        return np.frombuffer(a, np.int32, n).copy()
+
+    for qp in (0, 12, 23, 24, 35, 36, 51):
+        res = rng.integers(-255, 256, 16, dtype=np.int32)
+        lev = rng.integers(-300, 301, 16, dtype=np.int32)
+        dc = rng.integers(-4000, 4001, 16, dtype=np.int32)
+        for keep in (0, 1):
+            r = I4()
+            lib.forwardResidual(qp, arr(I4, res), r, C.c_ubyte(0), C.c_ubyte(keep))
+            assert np.array_equal(out(r, 16), fo.forward_residual(qp, res[None], keep)[0]), ("forwardResidual", qp, keep)
+            r = I4()
+            lib.inverseResidual(8, qp, arr(I4, lev), r, C.c_ubyte(keep))
+            assert np.array_equal(out(r, 16), fo.inverse_residual(qp, lev[None], keep)[0]), ("inverseResidual", qp, keep)
+        c = I4()
+        lib.forwardDCLumaIntra(qp, arr(I4, dc), c)
+        assert np.array_equal(out(c, 16), fo.block_op("forward_dc_luma_intra", dc[None], qp)[0])
+        c = I4()
+        lib.InverseDCLumaIntra(8, qp, arr(I4, lev), c)
+        assert np.array_equal(out(c, 16), fo.block_op("inverse_dc_luma_intra", lev[None], qp)[0])
+        c = I2()
+        lib.forwardDCChroma(qp, arr(I2, dc[:4]), c, C.c_ubyte(0))
+        assert np.array_equal(out(c, 4), fo.block_op("forward_dc_chroma", dc[None], qp)[0, :4])
+        c = I2()
+        lib.InverseDCChroma(8, qp, arr(I2, lev[:4]), c)
+        assert np.array_equal(out(c, 4), fo.block_op("inverse_dc_chroma", lev[None], qp)[0, :4])
+    lev = rng.integers(-300, 301, 16, dtype=np.int32)
+    for ac in (0, 1):
+        l = I16()
+        lib.transformScan(arr(I4, lev), l, C.c_ubyte(ac))
+        assert np.array_equal(out(l, 16 - ac), fo.block_op("transform_scan", lev[None], flag=bool(ac))[0, :16 - ac])
+    c = I4()
+    lib.transformInverseScan(arr(I16, lev), c)
+    assert np.array_equal(out(c, 16), fo.block_op("transform_inverse_scan", lev[None])[0])
+
+
 def test_randomised_configuration_sweep(pkg, fo):
     """A bounded slice of tools/sweep.py inside the suite: 20 random configurations (sizes, qp, WindowSize incl. the
     general path, MAXDIFF incl. adaptive and 0, IntraEvery, noise, still content = P_Skip heavy, flat / black boxes,
