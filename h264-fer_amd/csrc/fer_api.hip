@@ -152,6 +152,9 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
 {
     if (!out || !p || W <= 0 || H <= 0 || (W & 15) || (H & 15) || S <= 0 || W > 16384 || H > 16384) return FERHIP_E_ARG;
     if (p->qp < 0 || p->qp > 51 || p->window < 16 || p->intra_every <= 0) return FERHIP_E_ARG;
+    // the motion kernels address a stream's planes and records with 24-bit multiplies and 32-bit byte offsets: a padded
+    // plane stays below 2^24 samples (4K is 8.4 M; the reference itself stops at 10 000 macroblocks)
+    if (!decode_only && (size_t)(W + FER_IP_L + FER_IP_R) * (size_t)(H + FER_IP_T + FER_IP_B) >= ((size_t)1 << 24)) return FERHIP_E_UNSUP;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         fprintf(stderr, "ferhip: no HIP device; the hot path has no CPU fallback\n");

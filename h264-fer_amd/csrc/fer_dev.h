@@ -496,7 +496,10 @@ __device__ __forceinline__ void mc_luma4(const uint8_t *__restrict__ R, const IP
 {
     int X = xP + x + (mvx >> 2), Y = yP + y + (mvy >> 2);
     if (X >= 0 && X + 3 < W && Y >= 0 && Y < H) {
-        uint32_t v = load_u8x4(ip.base + (size_t)((mvy & 3) * 4 + (mvx & 3)) * ip.plane + (size_t)Y * ip.pitch + X);
+        // (32-bit byte offset from the stream's uniform plane base, 24-bit multiplies: a padded plane has < 2^24 samples)
+        const uint32_t o = __umul24((uint32_t)((mvy & 3) * 4 + (mvx & 3)), (uint32_t)ip.plane) + __umul24((uint32_t)Y, (uint32_t)ip.pitch) + (uint32_t)X;
+        const uint32_t *a = (const uint32_t *)(ip.base + (o & ~3u));  // planes start on 16-byte boundaries
+        const uint32_t v = __builtin_amdgcn_alignbyte(a[1], a[0], o & 3u);
         out[0] = v & 0xff;
         out[1] = (v >> 8) & 0xff;
         out[2] = (v >> 16) & 0xff;

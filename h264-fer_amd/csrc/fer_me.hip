@@ -345,7 +345,10 @@ __device__ __forceinline__ void local_metrics(const IPlanes &ip, int W, int H, i
         return;
     }
     const uint32_t sh = (uint32_t)(px0 & 3);
-    const uint8_t *pbase = ip.base + (ptrdiff_t)py0 * ip.pitch + (px0 & ~3);
+    // (a 32-bit byte offset from the stream's uniform plane base; the top-left of the patch may lie in the margin: ip.base
+    // points at sample (0, 0) behind it, so the offset is taken from the start of the margin)
+    const uint8_t *mbase = ip.base - ((size_t)FER_IP_T * ip.pitch + FER_IP_L);
+    const uint32_t obase = __umul24((uint32_t)(py0 + FER_IP_T), (uint32_t)ip.pitch) + (uint32_t)((px0 & ~3) + FER_IP_L);
     for (int half = half_lo; half < half_hi; half++) {
         // ---- horizontal sums: row tasks (plane, row)
 #pragma unroll
@@ -354,7 +357,7 @@ __device__ __forceinline__ void local_metrics(const IPlanes &ip, int W, int H, i
             const int tt = min(t, 8 * PW - 1);
             const int fl = tt / PW, r = tt - fl * PW;
             typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-            const u32x4_a4 w = *(const u32x4_a4 *)(pbase + (size_t)(half * 8 + fl) * ip.plane + (size_t)r * ip.pitch);
+            const u32x4_a4 w = *(const u32x4_a4 *)(mbase + (obase + __umul24((uint32_t)(half * 8 + fl), (uint32_t)ip.plane) + __umul24((uint32_t)r, (uint32_t)ip.pitch)));
             const uint32_t b0 = __builtin_amdgcn_alignbyte(w.y, w.x, sh), b1 = __builtin_amdgcn_alignbyte(w.z, w.y, sh),
                            b2 = __builtin_amdgcn_alignbyte(w.w, w.z, sh);
             if (t < 8 * PW) {
@@ -409,7 +412,7 @@ __device__ __forceinline__ void local_metrics(const IPlanes &ip, int W, int H, i
 __device__ __forceinline__ FeatRec feat0_load(const uint16_t *__restrict__ F0, int W, int H, int refy, int refx)
 {
     int y = iclamp(refy, 0, H - 1), x = iclamp(refx, 0, W - 1);
-    const uint32_t *r = (const uint32_t *)(F0 + ((size_t)y * W + x) * 6);
+    const uint32_t *r = (const uint32_t *)((const char *)F0 + (__umul24((uint32_t)y, (uint32_t)W * 12u) + (uint32_t)x * 12u));  // (a stream's map is < 4 GB, a row < 2^24 bytes)
     FeatRec f;
     f.a = r[0];
     f.b = r[1];
@@ -440,11 +443,12 @@ __device__ __forceinline__ int sad_lane(const IPlanes &ip, int W, int H, int sx,
 {
     const int xPi = iclamp(sx + (mvx >> 2), 0, W - 1), yPi = iclamp(sy + (mvy >> 2), 0, H - 1);
     const uint32_t sh = (uint32_t)(xPi & 3);  // planes and rows start on 16-byte boundaries
-    const uint8_t *p0 = ip.base + (size_t)((mvx & 3) + (mvy & 3) * 4) * ip.plane + (size_t)yPi * ip.pitch + (xPi & ~3);
+    // (32-bit byte offsets from the stream's uniform plane base: the 16 planes of a stream are < 4 GB)
+    const uint32_t o0 = __umul24((uint32_t)((mvx & 3) + (mvy & 3) * 4), (uint32_t)ip.plane) + __umul24((uint32_t)yPi, (uint32_t)ip.pitch) + (uint32_t)(xPi & ~3);
     uint32_t w[8][3];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const uint32_t *a = (const uint32_t *)(p0 + (size_t)r * ip.pitch);
+        const uint32_t *a = (const uint32_t *)(ip.base + (o0 + __umul24((uint32_t)r, (uint32_t)ip.pitch)));
         w[r][0] = a[0];
         w[r][1] = a[1];
         w[r][2] = a[2];
@@ -536,13 +540,15 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
             const int rx = sx - R + ix;
             const bool xok = rx >= 0 && rx < W;
             const int wx = iabs(ix - R) + 4;
-            const uint16_t *col = F0 + (size_t)iclamp(rx, 0, W - 1) * 6;
+            // (32-bit byte offsets from the stream's uniform base: a record load is one instruction with a scalar base,
+            // where 64-bit index arithmetic costs nine VALU instructions per load)
+            const uint32_t colo = (uint32_t)iclamp(rx, 0, W - 1) * 12u, rowb = (uint32_t)W * 12u;
             for (int iy0 = 0; iy0 < n; iy0 += RPB * WCH) {
                 FeatRec fr[WCH];
 #pragma unroll
                 for (int q = 0; q < WCH; q++) {
                     int ry = iclamp(sy - R + iy0 + q * RPB + r0, 0, H - 1);
-                    const uint32_t *r = (const uint32_t *)(col + (size_t)ry * W * 6);
+                    const uint32_t *r = (const uint32_t *)((const char *)F0 + (colo + __umul24((uint32_t)ry, rowb)));
                     fr[q].a = r[0];
                     fr[q].b = r[1];
                     fr[q].c = r[2];
@@ -704,8 +710,10 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
     // Descriptor of a batch, one per lane: first record; count (bits 0-6) | last batch of its step (bit 7) | step j
     // (bits 8-15) | bucket (bits 16-30) | side (bit 31: 0 = su[0] - j, 1 = su[0] + j).  Lanes beyond the last batch hold an empty batch at a readable address, so
     // the loop can fetch two batches ahead without tests.
+    const char *srec_s = (const char *)(srec + (size_t)g0 * 3);  // the stream's records: a uniform base + 32-bit byte offsets
     auto fetch = [&](unsigned b_start, int b_cnt, uint32_t &r0, uint32_t &r1, uint32_t &r2) {
-        const uint32_t *e = srec + (size_t)(b_start + (unsigned)min(lane, max(b_cnt - 1, 0))) * 3;
+        const uint32_t li = (b_start - g0) + (unsigned)min(lane, max(b_cnt - 1, 0));
+        const uint32_t *e = (const uint32_t *)(srec_s + __umul24(li, 12u));  // (a picture has fewer than 2^24 positions: ferhip_create)
         r0 = e[0];
         r1 = e[1];
         r2 = e[2];
@@ -1480,7 +1488,7 @@ __device__ __forceinline__ void resolve_crowded(const FerDev &d, int s, int sx, 
             }
             const int px = cx + dx, py = cy + dy;
             const bool inpic = px >= 0 && px < W && py >= 0 && py < H;
-            const uint32_t *rec = (const uint32_t *)(F0 + ((size_t)iclamp(py, 0, H - 1) * W + iclamp(px, 0, W - 1)) * 6);
+            const uint32_t *rec = (const uint32_t *)((const char *)F0 + (__umul24((uint32_t)iclamp(py, 0, H - 1), (uint32_t)W * 12u) + (uint32_t)iclamp(px, 0, W - 1) * 12u));
             const uint32_t a = rec[0], b = rec[1], c = rec[2];
             const int kk0 = (int)(a & 0xffffu), kk1 = (int)(a >> 16), kk2 = (int)(b & 0xffffu);
             const int j = iabs(kk0 - P.su[0]);

@@ -22,13 +22,13 @@ __device__ __forceinline__ void mc_chroma_row4(const uint8_t *__restrict__ R, in
 {
     const int by = (y >> 1) << 1, oy = y & 1;
     const int cy = yPc + by + (mvy >> 3);
-    const int y0 = iclamp(cy + oy, 0, Hc - 1) * Wc, y1 = iclamp(cy + oy + 1, 0, Hc - 1) * Wc;
+    const uint32_t y0 = __umul24((uint32_t)iclamp(cy + oy, 0, Hc - 1), (uint32_t)Wc), y1 = __umul24((uint32_t)iclamp(cy + oy + 1, 0, Hc - 1), (uint32_t)Wc);
     const int X = xPc + x + (mvx >> 3);  // x is a multiple of 4: sample k reads columns X + k and X + k + 1
     int t[5], u[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-        const int xc = iclamp(X + k, 0, Wc - 1);
-        t[k] = R[y0 + xc];
+        const uint32_t xc = (uint32_t)iclamp(X + k, 0, Wc - 1);
+        t[k] = R[y0 + xc];  // (32-bit offsets from the stream's uniform plane base)
         u[k] = R[y1 + xc];
     }
     const int xl = mvx & 7, yl = mvy & 7;

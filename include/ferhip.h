@@ -49,6 +49,8 @@ typedef struct {
 /* ---- context ---- */
 /* width/height: coded picture size, multiples of 16 (the reference crops to that,
  * F/fileIO.cpp:242-243).  nstreams: independent streams encoded side by side. */
+/* width, height: multiples of 16; an encoder context takes pictures of up to (width + 32) * (height + 16) < 2^24 samples
+ * (3840x2160 is half of that), larger ones return FERHIP_E_UNSUP */
 int ferhip_create(ferhip_ctx **out, int width, int height, int nstreams, const ferhip_params *p);
 void ferhip_destroy(ferhip_ctx *c);
 
