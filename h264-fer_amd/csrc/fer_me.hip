@@ -395,7 +395,7 @@ __device__ __forceinline__ void local_metrics(const IPlanes &ip, int W, int H, i
                 const uint32_t k4 = Pc[iy + 8] - Pc[iy];
                 const int D = feat_dist_w((all & 0xffffu) | (k1 << 16), (all >> 16) | (k3 << 16), k4, sp);
                 const int refy = py0 + iy;
-                const int m = (xok && refy >= 0 && refy < H) ? (wx + iabs(iy - R1)) * D : -1;
+                const int m = (int)__umul24((uint32_t)(wx + iabs(iy - R1)), (uint32_t)D) | ((xok && refy >= 0 && refy < H) ? 0 : -1);
                 mtab[((ix * N1 + iy) << 4) + half * 8 + fl] = m;
             }
         }
@@ -555,11 +555,13 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
                 }
 #pragma unroll
                 for (int q = 0; q < WCH; q++) {
-                    int iy = iy0 + q * RPB + r0;
-                    int ry = sy - R + iy;
-                    int m = (wx + iabs(iy - R)) * feat_dist_w(fr[q].a, fr[q].b, fr[q].c, sp);
-                    if (!(xok && ry >= 0 && ry < H)) m = -1;
-                    if (iy < n) wide_m[ix * n + iy] = m;
+                    // straight-line code: the validity test is a mask, rows beyond the window land in a spare slot
+                    // (the compiler otherwise wraps every candidate in two branches)
+                    const int iy = iy0 + q * RPB + r0;
+                    const int ry = sy - R + iy;
+                    const int m = (int)__umul24((uint32_t)(wx + iabs(iy - R)), (uint32_t)feat_dist_w(fr[q].a, fr[q].b, fr[q].c, sp));
+                    const int bad = (xok && ry >= 0 && ry < H) ? 0 : -1;
+                    wide_m[iy < n ? ix * n + iy : ME_WIDE_LDS - 1] = m | bad;
                 }
             }
             {  // column n - 1
@@ -1566,7 +1568,7 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
         for (int u = 0; u < FER_ST2_CAP / 64; u++) {
             int cc = u * 64 + lane;
             int tx = P.e2[u].x >> 16, ty = (int)(short)(P.e2[u].x & 0xffff);  // k_me_walk stores (tx << 16) | (ty & 0xffff)
-            m2[u] = cc < P.n2 ? (iabs(tx - genx) + iabs(ty - geny) + 4) * P.e2[u].y : -1;
+            m2[u] = (int)__umul24((uint32_t)(iabs(tx - genx) + iabs(ty - geny) + 4), (uint32_t)P.e2[u].y) | (cc < P.n2 ? 0 : -1);
         }
         auto raw2 = [&](int u) { return P.e2[u].x; };
         auto fin2 = [&](int e) { return pack_xy((e >> 16) * 4, (int)(short)(e & 0xffff) * 4); };
