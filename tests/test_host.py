@@ -34,6 +34,18 @@ def test_create_without_gpu_fails_loudly(pkg):
         pkg.FerHip(176, 144, 1)
 
 
+def test_encoder_picture_size_limit_is_reported(pkg):
+    """The motion kernels address a stream's planes with 24-bit multiplies: an encoder context refuses pictures whose padded
+    plane reaches 2^24 samples with FERHIP_E_UNSUP (-4) before anything touches the device (4K is half of the limit)."""
+    import ctypes as C
+    lib = pkg.load_library()
+    ctx = C.c_void_p()
+    from h264_fer_amd.ferhip import Params
+    p = Params(12, 0, 32, 3, 30)
+    assert lib.ferhip_create(C.byref(ctx), 4096, 4096, 1, C.byref(p)) == -4
+    assert lib.ferhip_create(C.byref(ctx), 4095, 4096, 1, C.byref(p)) == -1  # not a multiple of 16: FERHIP_E_ARG
+
+
 def test_synthetic_source_three_implementations_agree(pkg, fo):
     import torch
     from h264_fer_amd.synth import gen_frames_torch
