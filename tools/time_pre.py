@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
 from conftest import load_pkg
 pkg = load_pkg()
-W, H, S = 1920, 1072, 16
+W, H, S = 1920, 1072, int(os.environ.get("FER_TP_STREAMS", "16"))
 f0 = pkg.gen_frame(W, H, 0, 1234, 2); f1 = pkg.gen_frame(W, H, 1, 1234, 2)
 g = pkg.FerHip(W, H, S, qp=12, window=32, maxdiff=3, intra_every=30)
 g.set_reference(np.repeat(f0[None], S, 0)); g.set_frames(np.repeat(f1[None], S, 0))
