@@ -255,6 +255,12 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     rc |= dalloc(c, &d.st3n, decode_only ? (size_t)1 : (size_t)(nm * 4));
     rc |= dalloc(c, &d.st2, decode_only ? (size_t)1 : (size_t)(nm * 4 * FER_ST2_CAP * 2));
     rc |= dalloc(c, &d.st2n, decode_only ? (size_t)1 : (size_t)(nm * 4));
+    rc |= dalloc(c, &d.v0, decode_only ? (size_t)1 : (size_t)(nm * 4));
+    rc |= dalloc(c, &d.spec_hdr, decode_only ? (size_t)1 : (size_t)(nm * 4));
+    rc |= dalloc(c, &d.spec_l1, decode_only ? (size_t)1 : (size_t)(nm * 4 * 17));
+    rc |= dalloc(c, &d.spec_l2, decode_only ? (size_t)1 : (size_t)(nm * 4 * 33));
+    rc |= dalloc(c, &d.spec_stat, (size_t)8);
+    d.speculate = 1;
     rc |= dalloc(c, &d.chain, (size_t)64);
     rc |= dalloc(c, &d.timing, (size_t)64);
     rc |= dalloc(c, &d.chain64, decode_only ? (size_t)1 : (size_t)(nm * 4));
@@ -744,6 +750,10 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
             ProfScope ps(c, FERHIP_PH_ME_WALK, 1);
             fer_launch_me_walk(d, c->st);
         }
+        if (d.speculate) {
+            ProfScope ps(c, FERHIP_PH_ME_SPEC, 1);
+            fer_launch_me_spec(d, c->st);
+        }
         {
             // the per-diagonal chain is latency bound: run it on the high-priority stream so that its small
             // launches are dispatched ahead of other contexts' throughput kernels
@@ -923,12 +933,16 @@ extern "C" int ferhip_tune(ferhip_ctx *c, int key, int value)
     if (!c) return FERHIP_E_ARG;
     switch (key) {
     case FERHIP_TUNE_RESOLVE_WGS:
-        if (value < 1 || value > 65535) return FERHIP_E_ARG;
+        if (value < 1 || value > 65535) return FERHIP_E_ARG;  // (any grid takes every row: workgroups move from queue to queue)
         c->d.resolve_wgs = value;
         return 0;
     case FERHIP_TUNE_RESOLVE_GROUP:
         if (value < 1) return FERHIP_E_ARG;
-        c->d.resolve_group = value;
+        c->d.resolve_group = value < c->d.S ? value : c->d.S;  // (more streams than the context has add nothing)
+        return 0;
+    case FERHIP_TUNE_SPECULATE:
+        if (value != 0 && value != 1) return FERHIP_E_ARG;
+        c->d.speculate = value;
         return 0;
     default: return FERHIP_E_ARG;
     }
@@ -1007,6 +1021,10 @@ extern "C" int ferhip_inter_encoding(ferhip_ctx *c)
         ProfScope ps(c, FERHIP_PH_ME_WALK, 1);
         fer_launch_me_walk(c->d, c->st);
     }
+    if (c->d.speculate) {
+        ProfScope ps(c, FERHIP_PH_ME_SPEC, 1);
+        fer_launch_me_spec(c->d, c->st);
+    }
     {
         ProfScope ps(c, FERHIP_PH_ME_RESOLVE, 1);
         c->d.serial = c->d.serial % 0x7ffffff0 + 1;
@@ -1072,6 +1090,7 @@ extern "C" size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t
     case FERHIP_BUF_TIMING: src = d.timing; n = 64 * 8; break;
     case FERHIP_BUF_ST2N: src = d.st2n; n = nm * 16; break;
     case FERHIP_BUF_ST2: src = d.st2; n = nm * 4 * FER_ST2_CAP * 8; break;
+    case FERHIP_BUF_SPEC_STAT: src = d.spec_stat; n = 8 * 8; break;
     case FERHIP_BUF_CUR:
     case FERHIP_BUF_REF: {
         n = d.ysz * 3 / 2 * d.S;

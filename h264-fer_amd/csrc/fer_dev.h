@@ -96,6 +96,17 @@ struct FerDev {
     int *st3n;           // [S][nmb][4]
     int *st2;            // [S][nmb][4][CAP][2] (tmpx & 0xffff) | tmpy << 16, D
     int *st2n;           // [S][nmb][4]
+    // speculation on the predictor (k_me_spec -> k_me_resolve): v0 = the stage-3 survivor of smallest SAD, a guess of the
+    // partition's final vector that needs no neighbour; from the neighbours' v0 every partition gets a guessed predictor,
+    // and the two predictor-dependent searches are run for it in a fully parallel launch.  The chain only has to check
+    // the guess against the true predictor and price the stored lists.
+    int *v0;             // [S][nmb][4] packed vector
+    int4 *spec_hdr;      // [S][nmb][4]: x = guessed integer centre (genx & 0xffff | geny << 16), y = cnt1 | cnt2 << 8 |
+                         // lists valid << 16 | P_Skip verdict valid << 17, z = guessed P_Skip vector (partition 0), w = its verdict
+    int2 *spec_l1;       // [S][nmb][4][17] stage-1 list: (packed vector, SAD)
+    int2 *spec_l2;       // [S][nmb][4][33] stage-2 list
+    unsigned long long *spec_stat;  // [8] partitions the chain decided, hits, P_Skip verdicts needed, taken from the guess
+    int speculate;       // 0 = the chain searches everything itself (ferhip_tune; results do not depend on it)
     int *chain;          // row ticket of k_me_resolve
     unsigned long long *chain64;  // [S][nmb][4] vector | picture serial << 32 | P_Skip << 63, see k_me_resolve
     long long *timing;   // [64] in-kernel wall-clock sums of one probe wavefront (FER_DBG bit 7)
@@ -143,6 +154,7 @@ struct DecBatch {
 #define FER_ERR_DEC_SYNTAX 8
 #define FER_ERR_DEC_UNSUPPORTED 16
 #define FER_ERR_CHAIN_TIMEOUT 32
+#define FER_ERR_CHAIN_UNRESOLVED 64  // a P macroblock reached the residual stage without this picture's vectors
 
 // ---------------------------------------------------------------- tables
 // CAVLC tables: H.264 Tables 9-5, 9-7..9-10 as (length, code); zig-zag; block origins.

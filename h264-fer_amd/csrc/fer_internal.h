@@ -24,6 +24,7 @@ void fer_launch_sort_finish(const FerDev &d, FerSortTmp &t, hipStream_t st);
 void fer_launch_me_walk(const FerDev &d, hipStream_t st);
 void fer_launch_frame_sad(const FerDev &d, hipStream_t st);
 void fer_launch_me_pre(const FerDev &d, hipStream_t st);
+void fer_launch_me_spec(const FerDev &d, hipStream_t st);
 void fer_launch_me_resolve(const FerDev &d, hipStream_t st);
 void fer_launch_basic_stat(const FerDev &d, hipStream_t st);
 void fer_launch_p_resid(const FerDev &d, hipStream_t st);

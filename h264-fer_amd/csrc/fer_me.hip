@@ -12,12 +12,16 @@
 //                 16-byte feature records (walk_buckets_q, lane-held batch descriptor tables); partitions whose
 //                 candidate set overflows FER_ST2_CAP leave a summary (stop step, per-bucket lower bound, the
 //                 distance-0 list) instead of candidates;
-//   k_me_resolve  neighbour-dependent: P_Skip test, stage-1 search around the predictor, re-ranking of the stage-2
-//                 candidates (resolve_crowded: predictor-centred ring scan for overflowed partitions), final costs,
-//                 partition merge, mvd, final motion compensation and source snapping.  Persistent workgroups of
-//                 two wavefronts take (stream group, macroblock row) tickets from one queue per XCD and chain along
-//                 the row and to the row above through self-validating 64-bit words (chain64): no launch per
-//                 anti-diagonal, no grid-wide barrier.
+//   k_me_spec     neighbour-independent BY SPECULATION, one wavefront per partition: the predictor of every partition is
+//                 guessed from the neighbours' SAD-best stage-3 survivors, and the two searches that depend on it --
+//                 stage 1 around the predictor, the re-ranking of the stage-2 candidates (resolve_crowded: predictor-
+//                 centred ring scan for overflowed partitions) -- run for the guess and leave their lists with SADs;
+//   k_me_resolve  neighbour-dependent: the true predictor, P_Skip, and either the pricing of the guessed lists (the
+//                 guess was right: a few dozen instructions) or the chain's own search (it was wrong).  Persistent
+//                 workgroups of two wavefronts take (stream group, partition row) tickets from one queue per XCD,
+//                 stealing from the other queues when theirs is empty, and chain along the row and to the row above
+//                 through self-validating 64-bit words (chain64): no launch per anti-diagonal, no grid-wide barrier.
+//                 (Partition merge, mvd, final motion compensation and source snapping follow in k_p_resid.)
 //   k_basic_stat  BasicInterEncoding = 1 only: the counters the discarded exhaustive pass leaves behind.
 // The candidate list of MEstimation (F/moestimation.cpp:254-296) is a selection problem here -- the K smallest by
 // (metric, arrival) -- solved without serial insertion (select_topk); the ballot-ordered insertion (wl_insert)
@@ -511,7 +515,10 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
     su[4] = wave_sum((px & 3) > 1 ? 0 : v);
     if (lane < 5) d.suma[pidx * 5 + lane] = su[lane];
     if (d.basic) {  // BasicInterEncoding: stages 2 and 3 are not run (F/moestimation.cpp:470), only the sums are needed
-        if (lane == 0) d.st3n[pidx] = 0;
+        if (lane == 0) {
+            d.st3n[pidx] = 0;
+            d.v0[pidx] = 0;
+        }
         return;
     }
     const SuPk sp = su_pack(su);
@@ -643,6 +650,7 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
         }
     }
     const int n3 = __popcll(__ballot(lane < 33 && L.m < 100000000));
+    int v0 = 0;
     if (!FER_DBGF(d, 4)) {  // SADs of the survivors: list slot j lives in lane j
         const SrcBlk SB = src_block_load(Y, W, sx, sy);
         const int cx = unp_x(L.xy), cy = unp_y(L.xy);
@@ -653,8 +661,14 @@ __global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
             o[1] = cy;
             o[2] = sad;
         }
+        // the survivor of smallest SAD: a neighbour-independent guess of the partition's final vector (k_me_spec)
+        const int wk = wave_min(lane < n3 ? (sad << 6) | lane : 0x7fffffff);
+        if (wk != 0x7fffffff) v0 = lane_bcast(L.xy, wk & 63);
     }
-    if (lane == 0) d.st3n[pidx] = n3;
+    if (lane == 0) {
+        d.st3n[pidx] = n3;
+        d.v0[pidx] = v0;
+    }
 
 }
 
@@ -1151,14 +1165,16 @@ __device__ __forceinline__ void take_best(int best, int bestxy, int &bmin, int &
 // is running or finished, so every wait terminates; a bounded spin count turns anything
 // unexpected into an error flag instead of a hang.
 //
-// A wavefront that waits on its predecessor runs alone on its SIMD, so every dependent
-// instruction costs its full latency.  The two searches of a partition are therefore split over
-// the two wavefronts of the workgroup: wavefront 0 makes the P_Skip test, runs stage 1 (feature
-// records around the predictor, top 17, their SADs), merges and publishes; wavefront 1 re-ranks
-// the precomputed stage-2 set (top 33, their SADs) and the stage-3 survivors.  Both read the
-// neighbour vectors themselves; they meet twice per partition through LDS.
-// Everything after the vector of the partition is known (merge, mvd, final prediction,
-// snapping) is not on any other partition's dependency chain and lives in k_p_resid (fer_resid.hip).
+// The searches that depend on the predictor were run beforehand for a GUESSED predictor (k_me_spec): the common step
+// of the chain is "compute the true predictor, find that its integer part is the guessed one, price the stored
+// candidate lists" -- a few dozen dependent instructions, evaluated by both wavefronts of the workgroup alike.
+// After a wrong guess the chain searches itself.  A wavefront that waits on its predecessor runs alone on its SIMD, so
+// every dependent instruction costs its full latency; the two searches are therefore split over the two wavefronts of
+// the workgroup: wavefront 0 runs stage 1 (top 17 around the predictor, their SADs) and merges; wavefront 1 re-ranks
+// the precomputed stage-2 set (top 33, their SADs) and the stage-3 survivors; they meet through LDS.
+// Everything after the vector of the partition is known (merge, mvd, final prediction, snapping, and the
+// reconstruction of P_Skip macroblocks) is not on any other partition's dependency chain and lives in k_p_resid
+// (fer_resid.hip).
 #define ST1_UNROLL 7
 #define RES_SPIN_LIMIT (1 << 23)
 
@@ -1237,13 +1253,12 @@ __device__ __forceinline__ void wave_best(int best, int bestxy, int &wkey, int &
     if (wkey != 0x7fffffff) wxy = lane_bcast(bestxy, __ffsll((long long)__ballot(best == wkey)) - 1);
 }
 
-// role 0: P_Skip test (partition 0) and stage 1.  Returns skip; otherwise the best stage-1 (key, vector).
-// The on-chip features of stage 1's local search are built by BOTH wavefronts of the workgroup, 8 planes each (their own
-// row-sum tables, one table of metrics): wavefront 0 after the P_Skip test (resolve_stage1_front), wavefront 1 before its
-// stages 2 and 3 (resolve_local_back); a workgroup barrier later wavefront 0 selects and refines (resolve_stage1_rest).
+// The chain's own search (after a wrong guess).  The on-chip features of stage 1's local search are built by BOTH
+// wavefronts of the workgroup, 8 planes each (their own row-sum tables, one table of metrics: resolve_local_half); a
+// workgroup barrier later wavefront 0 selects and refines (resolve_stage1_rest) while wavefront 1 runs stages 2 and 3.
 #define RES_HTAB LocalGeo<2>::HTAB
 template <int WIN>
-__device__ __forceinline__ void resolve_local_half(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
+__device__ __forceinline__ void resolve_local_half(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, int genx, int geny,
                                                    uint32_t *loc_lds, int half)
 {
     if (FER_DBGF(d, 16)) return;
@@ -1252,98 +1267,66 @@ __device__ __forceinline__ void resolve_local_half(const FerDev &d, int s, int g
         const int window = WIN ? WIN : d.window;
         const int r1 = window / 16;
         const SuPk sp = su_pack(P.su);
-        int mvpx, mvpy;
-        predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
-        local_metrics<RR>(ip_stream(d, s), d.W, d.H, gx * 8 + (mvpx >> 2) - r1, gy * 8 + (mvpy >> 2) - r1, sp, lane, loc_lds + half * RES_HTAB,
+        local_metrics<RR>(ip_stream(d, s), d.W, d.H, gx * 8 + genx - r1, gy * 8 + geny - r1, sp, lane, loc_lds + half * RES_HTAB,
                           (int *)loc_lds + 2 * RES_HTAB, half, half + 1);
     }
 }
-template <int WIN>
-__device__ __forceinline__ void resolve_local_back(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
-                                                   uint32_t *loc_lds)
-{
-    resolve_local_half<WIN>(d, s, gx, gy, lane, P, N, loc_lds, 1);
-}
 
-// role 0, before the barrier: P_Skip test (partition 0) -> true = skip; otherwise the first half of the local features
-template <int WIN>
-__device__ __forceinline__ bool resolve_stage1_front(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
-                                                     uint32_t *loc_lds, int &skipw)
+// ---- P_Skip (F/mode_pred.cpp:381-402 + F/moestimation.cpp:402-425) ----
+// the vector of the P_Skip candidate: the 16x16 predictor, or zero at the picture's top / left edge and next to a zero
+// neighbour
+__device__ __forceinline__ void pskip_vector(const FerDev &d, int mb, int mbx, const ResNbr &N, int &smx, int &smy)
 {
-    const int window = WIN ? WIN : d.window;
-    const int mbx = gx >> 1, mby = gy >> 1, part = (gy & 1) * 2 + (gx & 1);
-    const int mb = mby * d.mbw + mbx;
-    const int W = d.W, H = d.H, Wc = d.Wc, Hc = d.Hc;
-    const size_t ysz = d.ysz, csz = d.csz;
-    uint8_t *Y = d.curY + (size_t)s * ysz;
-    const uint8_t *RY = d.refY + (size_t)s * ysz;
+    smx = smy = 0;
+    if (!(mb < d.mbw || mbx == 0)) {
+        const bool zu = N.B == 0, zl = N.A == 0;  // up MB quadrant 2, left MB quadrant 1
+        if (!(zu || zl)) predict_nbr(N.vA, N.A, N.vB, N.B, N.vC16, N.C16, N.vD, N.D, smx, smy);
+    }
+}
+// the test itself: every luma sample of the macroblock within MAXDIFF of its prediction.  A pure function of the
+// pictures and the vector (the reconstruction of a P_Skip macroblock is written by k_p_resid), so the speculative
+// pre-pass and both wavefronts of a chain workgroup may evaluate it.
+__device__ __forceinline__ bool pskip_test(const FerDev &d, int s, int mbx, int mby, int lane, int smx, int smy)
+{
+    const int W = d.W, H = d.H;
+    const uint8_t *Y = d.curY + (size_t)s * d.ysz;
+    const uint8_t *RY = d.refY + (size_t)s * d.ysz;
     const IPlanes ip = ip_stream(d, s);
     const int xp = mbx << 4, yp = mby << 4;
-    const int sx = gx * 8, sy = gy * 8;
-    skipw = 0;
-
-    if (part == 0) {
-        // ---- P_Skip candidate, F/mode_pred.cpp:381-402 + F/moestimation.cpp:402-425
-        // each lane owns 4 luma samples (lx..lx+3, ly) and one sample of each chroma plane
-        const int lx = (lane & 3) * 4, ly = lane >> 2;
-        const int cxl = lane & 7, cyl = lane >> 3;
-        int smx = 0, smy = 0;
-        if (!(mb < d.mbw || mbx == 0)) {
-            bool zu = N.B == 0, zl = N.A == 0;  // up MB quadrant 2, left MB quadrant 1
-            if (!(zu || zl)) predict_nbr(N.vA, N.A, N.vB, N.B, N.vC16, N.C16, N.vD, N.D, smx, smy);
-        }
-        int srcv[4], pred[4];
-        uint32_t sv = *(const uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx);
+    // each lane owns 4 luma samples (lx..lx+3, ly)
+    const int lx = (lane & 3) * 4, ly = lane >> 2;
+    int srcv[4], pred[4];
+    const uint32_t sv = *(const uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx);
 #pragma unroll
-        for (int k = 0; k < 4; k++) srcv[k] = (sv >> (8 * k)) & 0xff;
-        mc_luma4(RY, ip, W, H, xp, yp, lx, ly, smx, smy, pred);
-        int MAXDIFF = d.maxdiff_set;
-        if (d.maxdiff_set == -1) {  // adaptive tolerance, F/moestimation.cpp:407-419
-            int mean = wave_sum(srcv[0] + srcv[1] + srcv[2] + srcv[3]) / 256;
-            int dev = wave_sum(iabs(srcv[0] - mean) + iabs(srcv[1] - mean) + iabs(srcv[2] - mean) + iabs(srcv[3] - mean));
-            MAXDIFF = dev / 256;
-            if (MAXDIFF < 3) MAXDIFF = 3;
-        }
-        bool exact = true;
-#pragma unroll
-        for (int k = 0; k < 4; k++) exact = exact && iabs(srcv[k] - pred[k]) <= MAXDIFF;
-        if (__all(exact)) {
-            // P_Skip: reconstruction == prediction (F/inttransform.cpp:215-231)
-            uint8_t *Cb = d.curCb + (size_t)s * csz, *Cr = d.curCr + (size_t)s * csz;
-            const uint8_t *RCb = d.refCb + (size_t)s * csz, *RCr = d.refCr + (size_t)s * csz;
-            *(uint32_t *)(Y + (size_t)(yp + ly) * W + xp + lx) =
-                (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
-            Cb[(size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl] = (uint8_t)mc_chroma(RCb, Wc, Hc, xp / 2, yp / 2, cxl, cyl, smx, smy);
-            Cr[(size_t)(yp / 2 + cyl) * Wc + xp / 2 + cxl] = (uint8_t)mc_chroma(RCr, Wc, Hc, xp / 2, yp / 2, cxl, cyl, smx, smy);
-            skipw = pack_xy(smx, smy);
-            return true;
-        }
+    for (int k = 0; k < 4; k++) srcv[k] = (sv >> (8 * k)) & 0xff;
+    mc_luma4(RY, ip, W, H, xp, yp, lx, ly, smx, smy, pred);
+    int MAXDIFF = d.maxdiff_set;
+    if (d.maxdiff_set == -1) {  // adaptive tolerance, F/moestimation.cpp:407-419
+        int mean = wave_sum(srcv[0] + srcv[1] + srcv[2] + srcv[3]) / 256;
+        int dev = wave_sum(iabs(srcv[0] - mean) + iabs(srcv[1] - mean) + iabs(srcv[2] - mean) + iabs(srcv[3] - mean));
+        MAXDIFF = dev / 256;
+        if (MAXDIFF < 3) MAXDIFF = 3;
     }
-    resolve_local_half<WIN>(d, s, gx, gy, lane, P, N, loc_lds, 0);
-    return false;
+    bool exact = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) exact = exact && iabs(srcv[k] - pred[k]) <= MAXDIFF;
+    return __all(exact);
 }
 
-// role 0, after the barrier: stage 1 proper -> the best (key, vector)
+// ---- stage 1: +-W/16 around the integer centre (genx, geny), all 16 fractional planes (K = 17) -> the list, its length.
+// WindowSize 16 / 32: the metrics are in mtab (local_metrics, whoever ran it).  Depends on the predictor through its
+// integer part only.
 template <int WIN>
-__device__ __forceinline__ void resolve_stage1_rest(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
-                                                    int *sel_lds, uint32_t *loc_lds, int &wkey, int &wxy)
+__device__ __forceinline__ int stage1_list(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, int genx, int geny,
+                                           int *sel_lds, const int *mtab, WList &L1)
 {
     const int window = WIN ? WIN : d.window;
     const int W = d.W, H = d.H;
-    const IPlanes ip = ip_stream(d, s);
     const int sx = gx * 8, sy = gy * 8;
-    wkey = 0x7fffffff;
-    wxy = 0;
-    // ---- stage 1: +-W/16 around the predictor, all 16 fractional planes (K = 17)
-    const SuPk sp = su_pack(P.su);
-    int mvpx, mvpy;
-    predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
-    const int genx = mvpx >> 2, geny = mvpy >> 2;
-    if (FER_DBGF(d, 16)) return;  // (probe: the chain without stage 1)
-    WList L1;
     L1.m = INF_M;
     L1.xy = 0;
-    const int r1 = window / 16, n1 = 2 * r1 + 1, tot1 = FER_DBGF(d, 16) ? 0 : n1 * n1 * 16;
+    if (FER_DBGF(d, 16)) return 0;  // (probe: the chain without stage 1)
+    const int r1 = window / 16, n1 = 2 * r1 + 1, tot1 = n1 * n1 * 16;
     auto raw1 = [&](int u) { return u * 64 + lane; };  // arrival index
     auto fin1 = [&](int cc) {
         int frac = cc & 15, pos = cc >> 4;
@@ -1354,9 +1337,11 @@ __device__ __forceinline__ void resolve_stage1_rest(const FerDev &d, int s, int 
         constexpr int NB1 = LocalGeo<RR>::NB;
         int m[NB1];
 #pragma unroll
-        for (int u = 0; u < NB1; u++) m[u] = ((const int *)loc_lds)[2 * RES_HTAB + u * 64 + lane];
+        for (int u = 0; u < NB1; u++) m[u] = mtab[u * 64 + lane];
         select_topk<NB1>(m, 17, lane, sel_lds, L1, raw1, fin1);
     } else {
+        const SuPk sp = su_pack(P.su);
+        const IPlanes ip = ip_stream(d, s);
         for (int base = 0; base < tot1; base += 64) {
             int cc = base + lane;
             int frac = cc & 15, pos = cc >> 4;
@@ -1371,9 +1356,21 @@ __device__ __forceinline__ void resolve_stage1_rest(const FerDev &d, int s, int 
             wl_insert(L1, 17, lane, ok, m, pack_xy(tx * 4 + (frac & 3), ty * 4 + (frac >> 2)));
         }
     }
-    const int cnt1 = __popcll(__ballot(lane < 17 && L1.m < 100000000));
+    return __popcll(__ballot(lane < 17 && L1.m < 100000000));
+}
+
+// role 0 of the chain's own search, after the barrier: stage 1 proper -> the best (key, vector)
+template <int WIN>
+__device__ __forceinline__ void resolve_stage1_rest(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, int mvpx, int mvpy,
+                                                    int *sel_lds, uint32_t *loc_lds, int &wkey, int &wxy)
+{
+    wkey = 0x7fffffff;
+    wxy = 0;
+    WList L1;
+    const int cnt1 = stage1_list<WIN>(d, s, gx, gy, lane, P, mvpx >> 2, mvpy >> 2, sel_lds, (const int *)loc_lds + 2 * RES_HTAB, L1);
+    if (FER_DBGF(d, 16)) return;
     int b1, b1xy;
-    sad_keys<17>(L1, cnt1, lane, ip, W, H, sx, sy, P.sb, mvpx, mvpy, b1, b1xy);
+    sad_keys<17>(L1, cnt1, lane, ip_stream(d, s), d.W, d.H, gx * 8, gy * 8, P.sb, mvpx, mvpy, b1, b1xy);
     wave_best(b1, b1xy, wkey, wxy);
 }
 
@@ -1526,23 +1523,15 @@ __device__ __forceinline__ void resolve_crowded(const FerDev &d, int s, int sx, 
     L2.xy = L.xy;
 }
 
-// role 1: stage 2 (K = 33 of the precomputed candidate set, weighted by the distance to the predictor)
-// and stage 3 (precomputed survivors): best (key, vector) of each
-template <int WIN>
-__device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, const ResNbr &N,
-                                                int *sel_lds, int &k2, int &xy2, int &k3, int &xy3)
+// ---- stage 2: K = 33 of the precomputed candidate set, weighted by the distance to the integer centre (genx, geny)
+// -> the list, its length.  Depends on the predictor through its integer part only.
+__device__ __forceinline__ int stage2_list(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, int genx, int geny,
+                                           int *sel_lds, WList &L2)
 {
-    const int W = d.W, H = d.H;
-    const size_t ysz = d.ysz;
-    const IPlanes ip = ip_stream(d, s);
     const int sx = gx * 8, sy = gy * 8;
-    k2 = k3 = 0x7fffffff;
-    xy2 = xy3 = 0;
-    if (d.basic || FER_DBGF(d, 32)) return;
-    int mvpx, mvpy;
-    predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
-    const int genx = mvpx >> 2, geny = mvpy >> 2;
-    WList L2;
+    L2.m = INF_M;
+    L2.xy = 0;
+    if (d.basic || FER_DBGF(d, 32)) return 0;
     // a crowded partition without a big slice whose candidates did not fit the list (a few hundred of them, all in small
     // slices): reading them again costs little
     const uint32_t cfl = (uint32_t)lane_bcast(P.e2[0].y, 41);
@@ -1552,8 +1541,6 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
     } else if (P.n2raw > FER_ST2_CAP) {
         // crowded AND the reference's mis-filed bucket layout (black areas), or the case above: walk the buckets again,
         // now that the predictor is known, through an exact running top-33 (ordered insertion = the reference's own list update)
-        L2.m = INF_M;
-        L2.xy = 0;
         const SuPk sp = su_pack(P.su);
         int jx;
         walk_buckets(d, s, P.su, sp, sx, sy, lane, (uint32_t *)sel_lds, 0x7fffffff, jx, [&](bool ok, int rank, int rel, int D, uint32_t) {
@@ -1574,14 +1561,128 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
         auto fin2 = [&](int e) { return pack_xy((e >> 16) * 4, (int)(short)(e & 0xffff) * 4); };
         select_topk<FER_ST2_CAP / 64>(m2, 33, lane, sel_lds, L2, raw2, fin2);
     }
-    const int cnt2 = __popcll(__ballot(lane < 33 && L2.m < 100000000));
+    return __popcll(__ballot(lane < 33 && L2.m < 100000000));
+}
+
+// role 1 of the chain's own search: stage 2 and stage 3 (precomputed survivors): best (key, vector) of each
+template <int WIN>
+__device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, int mvpx, int mvpy,
+                                                int *sel_lds, int &k2, int &xy2, int &k3, int &xy3)
+{
+    k2 = k3 = 0x7fffffff;
+    xy2 = xy3 = 0;
+    if (d.basic || FER_DBGF(d, 32)) return;
+    WList L2;
+    const int cnt2 = stage2_list(d, s, gx, gy, lane, P, mvpx >> 2, mvpy >> 2, sel_lds, L2);
     if (FER_DBGF(d, 256)) L2.xy = pack_xy(lane & 7, lane >> 3);  // (probe: what the scattered SAD rows of stage 2 cost)
     int b2, b2xy;
-    sad_keys<33>(L2, cnt2, lane, ip, W, H, sx, sy, P.sb, mvpx, mvpy, b2, b2xy);
+    sad_keys<33>(L2, cnt2, lane, ip_stream(d, s), d.W, d.H, gx * 8, gy * 8, P.sb, mvpx, mvpy, b2, b2xy);
     wave_best(b2, b2xy, k2, xy2);
     int key = 0x7fffffff;
     if (lane < P.n3) key = ((P.c3s + iabs(P.c3x - mvpx) + iabs(P.c3y - mvpy)) << 6) | lane;
     wave_best(key, pack_xy(P.c3x, P.c3y), k3, xy3);
+}
+
+// neighbour vectors of partition (gx, gy) out of a per-stream array of packed vectors [nmb][4] (the guesses v0)
+__device__ __forceinline__ ResNbr nbr_from_field(const FerDev &d, const int *vf, int gx, int gy, int lane)
+{
+    const int part = (gy & 1) * 2 + (gx & 1), mbx = gx >> 1, mby = gy >> 1;
+    const int x = (part & 1) * 8, y = (part >> 1) * 8;
+    bool val = false;
+    int mbN = 0, q = 0;
+    // lane 0 = B, 1 = C, 2 = D, 3 = C of the 16x16 (P_Skip) predictor, 4 = A
+    if (lane < 5 && (lane != 3 || part == 0)) {
+        const int nx = lane == 0 ? x : (lane == 1 ? x + 8 : (lane == 3 ? 16 : x - 1));
+        const int ny = lane == 3 ? -1 : (lane == 4 ? y : y - 1);
+        nbr_locate_xy(d.mbw, mbx, mby, nx, ny, val, mbN, q);
+    }
+    const int w = val ? vf[(size_t)mbN * 4 + q] : 0;
+    const unsigned long long vm = __ballot(val);
+    ResNbr N;
+    N.vB = vm & 1;
+    N.vC = (vm >> 1) & 1;
+    N.vD = (vm >> 2) & 1;
+    N.vC16 = (vm >> 3) & 1;
+    N.vA = (vm >> 4) & 1;
+    N.B = lane_bcast(w, 0);
+    N.C = lane_bcast(w, 1);
+    N.D = lane_bcast(w, 2);
+    N.C16 = lane_bcast(w, 3);
+    N.A = lane_bcast(w, 4);
+    return N;
+}
+
+// ------------------------------------------------------------------ k_me_spec
+// The two searches of interEncoding that depend on the neighbours (stage 1 around the predictor, the re-ranking of the
+// stage-2 set; F/moestimation.cpp:458-496) depend on them through ONE number pair: the integer part of the predicted
+// vector.  It is guessed here for every partition from the neighbours' v0 (the SAD-best stage-3 survivor, k_me_pre),
+// and both searches run for the guess in a fully parallel launch -- a workgroup per macroblock, a wavefront per 8x8
+// partition -- that leaves their candidate lists with the SAD of every candidate.  k_me_resolve then only checks the
+// guess against the true predictor and prices the lists (SAD + |mv - mvp|); a wrong guess sends it through its own search.
+// Partition 0 also tries the P_Skip test for the guessed P_Skip vector; when it passes, the other three wavefronts skip
+// their searches (the macroblock will most likely be skipped).
+template <int WIN>
+__global__ __launch_bounds__(256) void k_me_spec(FerDev d)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t loc_all[4][LocalGeo<2>::HTAB + LocalGeo<2>::NB * 64];  // row sums (later the selection's scratch), metrics
+    __shared__ int skipflag;
+    static_assert(LocalGeo<2>::HTAB >= 256, "the selection's scratch fits the row sums");
+    const int lane = threadIdx.x & 63;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = blockIdx.y;
+    if (d.hdr[s * 4 + 3] != 0) return;
+    const int mb = (int)xcd_swizzle(blockIdx.x, gridDim.x);
+    const int mbx = mb % d.mbw, mby = mb / d.mbw;
+    const int gx = mbx * 2 + (part & 1), gy = mby * 2 + (part >> 1);
+    const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
+    uint32_t *htab = loc_all[part];
+    int *mtab = (int *)loc_all[part] + LocalGeo<2>::HTAB;
+    int *sel_lds = (int *)loc_all[part];  // the row sums are dead when the selections start
+    const ResNbr N = nbr_from_field(d, d.v0 + (size_t)s * d.nmb * 4, gx, gy, lane);
+    ResPre P;
+    res_prefetch(d, s, gx, gy, lane, 1, P);
+    int smw = 0;
+    bool sk = false;
+    if (part == 0) {
+        int smx, smy;
+        pskip_vector(d, mb, mbx, N, smx, smy);
+        smw = pack_xy(smx, smy);
+        sk = pskip_test(d, s, mbx, mby, lane, smx, smy);
+        if (lane == 0) skipflag = sk;
+    }
+    __syncthreads();
+    sk = skipflag != 0;
+    int mvpx, mvpy;
+    predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
+    const int genx = mvpx >> 2, geny = mvpy >> 2;
+    const int genw = pack_xy(genx, geny);
+    if (sk) {  // no lists: if the chain finds the macroblock is not skipped after all, it searches itself
+        if (lane == 0) d.spec_hdr[pidx] = make_int4(genw, part == 0 ? (1 << 17) : 0, smw, 1);
+        return;
+    }
+    const int W = d.W, H = d.H;
+    const IPlanes ip = ip_stream(d, s);
+    const int sx = gx * 8, sy = gy * 8;
+    if (WIN == 32 || WIN == 16) {
+        constexpr int RR = (WIN ? WIN : 32) / 16;
+        local_metrics<RR>(ip, W, H, sx + genx - RR, sy + geny - RR, su_pack(P.su), lane, htab, mtab);
+    }
+    WList L1, L2;
+    const int cnt1 = stage1_list<WIN>(d, s, gx, gy, lane, P, genx, geny, sel_lds, mtab, L1);
+    {
+        const bool on = lane < cnt1;
+        const int cx = on ? unp_x(L1.xy) : 0, cy = on ? unp_y(L1.xy) : 0;
+        const int sad = sad_lane(ip, W, H, sx, sy, cx, cy, P.sb);
+        if (on) d.spec_l1[pidx * 17 + lane] = make_int2(L1.xy, sad);
+    }
+    const int cnt2 = stage2_list(d, s, gx, gy, lane, P, genx, geny, sel_lds, L2);
+    {
+        const bool on = lane < cnt2;
+        const int cx = on ? unp_x(L2.xy) : 0, cy = on ? unp_y(L2.xy) : 0;
+        const int sad = sad_lane(ip, W, H, sx, sy, cx, cy, P.sb);
+        if (on) d.spec_l2[pidx * 33 + lane] = make_int2(L2.xy, sad);
+    }
+    if (lane == 0) d.spec_hdr[pidx] = make_int4(genw, cnt1 | (cnt2 << 8) | (1 << 16) | (part == 0 ? (1 << 17) : 0), smw, 0);
 }
 
 template <int WIN>
@@ -1597,27 +1698,36 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
     // Row tickets: rows of all streams in row-major order.  The launch is capped at a share of the GPU's
     // workgroup slots (other contexts' kernels keep finding free slots); a workgroup that finishes a row takes
     // the next ticket.
+    // One ticket queue per XCD (when there are enough streams): stream s belongs to queue s % 8, and a queue hands out
+    // its streams `resolve_group` at a time, row-major inside the group.  A workgroup starts on the queue of the XCD it
+    // runs on (HW_REG_XCC_ID), so all rows of a stream normally run on ONE XCD: what a partition reads was fetched into that
+    // XCD's L2 by the row above a few steps earlier.  When its queue is exhausted the workgroup moves on to the next
+    // queue: every row is taken whatever the placement of the workgroups (a grid smaller than 8, a CU mask, a partition
+    // mode), and the tail of a picture is shared.  Tickets of one queue are taken in order, so the row a workgroup waits
+    // on was claimed before its own by a workgroup that is running or finished: every wait terminates.
     int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     const int nq = d.S >= 16 ? 8 : 1;                 // queues
-    const int q = nq == 8 ? (xcc & 7) : 0;            // this workgroup's queue
-    const int nsq = (d.S - q + nq - 1) / nq;          // streams q, q + nq, ... of the queue
+    const int q_own = nq == 8 ? (xcc & 7) : 0;        // where this workgroup starts
+    int q_done = 0;                                   // queues found exhausted
+    const bool spec = d.speculate != 0;
+    unsigned st_parts = 0, st_hits = 0, st_skq = 0, st_skh = 0;
     for (;;) {
     __syncthreads();
-    // One ticket queue per XCD (when there are enough streams): stream s belongs to XCD s % 8, and an XCD takes its
-    // streams `resolve_group` at a time, row-major inside the group.  All rows of a stream then run on ONE XCD: the
-    // window a partition reads was fetched into that XCD's L2 by the row above a few steps earlier, and the rows in
-    // flight belong to few streams, so the working set fits.  Which XCD a workgroup runs on is read from the hardware
-    // (HW_REG_XCC_ID); nothing depends on how workgroups are placed.
-    if (threadIdx.x == 0) xch[0] = atomicAdd(d.chain + q, 1);
+    const int qu = (q_own + q_done) & (nq - 1);
+    const int nsq = (d.S - qu + nq - 1) / nq;         // streams qu, qu + nq, ... of the queue
+    if (threadIdx.x == 0) xch[0] = atomicAdd(d.chain + qu, 1);
     __syncthreads();
     const int t = xch[0];
     __syncthreads();
     const int G = d.resolve_group;
     const int grp = t / (gh * G), rr = t - grp * (gh * G);
     const int k0 = grp * G, kn = min(G, nsq - k0);  // streams of this group, as indices into the queue's stream list
-    if (k0 >= nsq) return;
-    const int gy = rr / kn, s = q + nq * (k0 + (rr - gy * kn));
+    if (k0 >= nsq) {
+        if (++q_done == nq) break;
+        continue;
+    }
+    const int gy = rr / kn, s = qu + nq * (k0 + (rr - gy * kn));
     if (gy >= gh) continue;  // short last group: its tickets beyond gh * kn name no row
     if (d.hdr[s * 4 + 3] != 0) continue;  // not a P picture: nobody waits on these rows
     unsigned long long *chw = d.chain64 + (size_t)s * d.nmb * 4;
@@ -1645,12 +1755,28 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
         const int part = (gy & 1) * 2 + (gx & 1);
         const int mbx = gx >> 1, mby = gy >> 1;
         const int mb = mby * d.mbw + mbx;
+        const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
         // the lane id is made opaque per iteration: otherwise dozens of lane-derived constants of the loop body
         // are hoisted out of the loop and spilled
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        ResPre cur;  // requested before the neighbours are polled: both round trips overlap
-        res_prefetch(d, s, gx, gy, ln, role, cur);
+        // what the guessed search left behind, requested before the neighbours are polled (both round trips overlap):
+        // the lane's entry of either list and of the stage-3 survivors
+        int4 sh = make_int4(0, 0, 0, 0);
+        int2 e1 = make_int2(0, 0), e2 = make_int2(0, 0);
+        int c3x = 0, c3y = 0, c3s = 0, n3 = 0;
+        if (spec) {
+            sh = d.spec_hdr[pidx];
+            e1 = d.spec_l1[pidx * 17 + min(ln, 16)];
+            e2 = d.spec_l2[pidx * 33 + min(ln, 32)];
+            if (!d.basic) {
+                const int *c3 = d.st3 + (pidx * 33 + min(ln, 32)) * 3;
+                c3x = c3[0];
+                c3y = c3[1];
+                c3s = c3[2];
+                n3 = d.st3n[pidx];
+            }
+        }
         // neighbours in the row above: lane 0 = B, 1 = C, 2 = D, 3 = C of the 16x16 (P_Skip) predictor
         const int x = (part & 1) * 8, y = (part >> 1) * 8;
         bool val = false;
@@ -1693,87 +1819,117 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
             skip = (lane_bcast((int)wh, 0) & CH_SKIP) != 0;
             if (skip) prevw = N.B;
         }
-        if (part == 0 || !skip) {  // the same decision in both wavefronts: the barriers below are uniform
-#ifdef FER_PROBE
-            const long long tst = wall_clock64();
-#endif
+        if (part == 0 || !skip) {
+            // Both wavefronts of the workgroup hold the same neighbours and come to the same decisions: P_Skip and the
+            // pricing of the guessed lists are evaluated by both (no barrier on the common path); only the chain's own
+            // search, after a wrong guess, splits the work and meets at barriers -- which both reach or both do not.
+            bool sk = false;
+            int r = 0;
+            if (part == 0) {  // ---- P_Skip candidate
+                int smx, smy;
+                pskip_vector(d, mb, mbx, N, smx, smy);
+                r = pack_xy(smx, smy);
+                st_skq++;
+                if (((sh.y >> 17) & 1) && sh.z == r) {
+                    sk = sh.w != 0;
+                    st_skh++;
+                } else {
+                    sk = pskip_test(d, s, mbx, mby, ln, smx, smy);
+                }
+            }
+            if (!sk) {
+                int mvpx, mvpy;
+                predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
+                st_parts++;
+                if (((sh.y >> 16) & 1) && sh.x == pack_xy(mvpx >> 2, mvpy >> 2)) {
+                    // ---- the guess was right: cost = SAD + |mv - mvp| over the three lists; the reference's ordered
+                    // first minimum (stage 1, 2, 3 in turn, strict <, F/moestimation.cpp:460-520) is the minimum of
+                    // cost << 8 | stage << 6 | list index
+                    st_hits++;
+                    const int cnt1 = sh.y & 255, cnt2 = (sh.y >> 8) & 255;
+                    int key = 0x7fffffff, kxy = 0;
+                    if (ln < cnt1) {
+                        key = ((e1.y + iabs(unp_x(e1.x) - mvpx) + iabs(unp_y(e1.x) - mvpy)) << 8) | ln;
+                        kxy = e1.x;
+                    }
+                    if (ln < cnt2) {
+                        const int k2 = ((e2.y + iabs(unp_x(e2.x) - mvpx) + iabs(unp_y(e2.x) - mvpy)) << 8) | 64 | ln;
+                        if (k2 < key) {
+                            key = k2;
+                            kxy = e2.x;
+                        }
+                    }
+                    if (ln < n3) {
+                        const int k3 = ((c3s + iabs(c3x - mvpx) + iabs(c3y - mvpy)) << 8) | 128 | ln;
+                        if (k3 < key) {
+                            key = k3;
+                            kxy = pack_xy(c3x, c3y);
+                        }
+                    }
+                    int wkey;
+                    wave_best(key, kxy, wkey, r);
+                } else {
+                    // ---- the chain's own search: wavefront 0 stage 1, wavefront 1 stages 2 and 3
+                    ResPre cur;
+                    res_prefetch(d, s, gx, gy, ln, role, cur);
+                    resolve_local_half<WIN>(d, s, gx, gy, ln, cur, mvpx >> 2, mvpy >> 2, loc_lds, role);
+                    __syncthreads();  // both halves of the local features are in place
+                    if (role == 0) {
+                        int k1, xy1;
+                        resolve_stage1_rest<WIN>(d, s, gx, gy, ln, cur, mvpx, mvpy, sel_lds, loc_lds, k1, xy1);
+                        PR_MARK(1)
+                        __syncthreads();  // stage 2/3 results are in xch[0..3]
+                        PR_MARK(2)
+                        int bmin = 2000000000;  // ordered first minimum over stage 1, 2, 3 (strict <)
+                        r = 0;
+                        if (k1 != 0x7fffffff && (k1 >> 6) < bmin) {
+                            bmin = k1 >> 6;
+                            r = xy1;
+                        }
+                        const int k2 = xch[0], k3 = xch[2];
+                        if (k2 != 0x7fffffff && (k2 >> 6) < bmin) {
+                            bmin = k2 >> 6;
+                            r = xch[1];
+                        }
+                        if (k3 != 0x7fffffff && (k3 >> 6) < bmin) {
+                            bmin = k3 >> 6;
+                            r = xch[3];
+                        }
+                        if (ln == 0) xch[4] = r;
+                        __syncthreads();
+                    } else {
+                        int k2, xy2, k3, xy3;
+                        resolve_stage23<WIN>(d, s, gx, gy, ln, cur, mvpx, mvpy, sel_lds, k2, xy2, k3, xy3);
+                        if (ln == 0) {
+                            xch[0] = k2;
+                            xch[1] = xy2;
+                            xch[2] = k3;
+                            xch[3] = xy3;
+                        }
+                        PR_MARK(1)
+                        __syncthreads();
+                        PR_MARK(2)
+                        __syncthreads();  // the merged result is in xch[4]
+                        r = xch[4];
+                    }
+                }
+            }
             if (role == 0) {
-                int skipw, k1 = 0x7fffffff, xy1 = 0;
-                const bool sk = resolve_stage1_front<WIN>(d, s, gx, gy, ln, cur, N, loc_lds, skipw);
-                __syncthreads();  // the other half of the local features is in place
-                if (!sk) resolve_stage1_rest<WIN>(d, s, gx, gy, ln, cur, N, sel_lds, loc_lds, k1, xy1);
-#ifdef FER_PROBE
-                if (FER_DBGF(d, 128) && s == 0 && lane == 0)  // the slowest stage-1 call of the picture and where it was
-                    atomicMax((unsigned long long *)&d.timing[40], ((unsigned long long)(wall_clock64() - tst) << 24) | ((unsigned long long)gx << 12) | (unsigned long long)gy);
-#endif
-                PR_MARK(1)
-                __syncthreads();  // stage 2/3 results are in xch[0..3]
-                PR_MARK(2)
-                int r = skipw;
-                if (!sk) {  // ordered first minimum over stage 1, 2, 3 (strict <, F/moestimation.cpp:460-520)
-                    int bmin = 2000000000;
-                    r = 0;
-                    if (k1 != 0x7fffffff && (k1 >> 6) < bmin) {
-                        bmin = k1 >> 6;
-                        r = xy1;
-                    }
-                    const int k2 = xch[0], k3 = xch[2];
-                    if (k2 != 0x7fffffff && (k2 >> 6) < bmin) {
-                        bmin = k2 >> 6;
-                        r = xch[1];
-                    }
-                    if (k3 != 0x7fffffff && (k3 >> 6) < bmin) {
-                        bmin = k3 >> 6;
-                        r = xch[3];
-                    }
-                }
-                if (ln == 0) {
-                    xch[4] = r;
-                    xch[5] = sk;
-                }
-                unsigned long long w = (unsigned)r | ((unsigned long long)(serial | (sk ? CH_SKIP : 0u)) << 32);
+                const unsigned long long w = (unsigned)r | ((unsigned long long)(serial | (sk ? CH_SKIP : 0u)) << 32);
                 if (part == 0 && ln == 0) {
                     mbt[mb] = sk ? FER_P_SKIP : FER_P_8x8ref0;  // also clears a P_Skip left by the previous picture
                     // BasicInterEncoding makes the P_Skip test twice and counts it twice (F/moestimation.cpp:324,421)
                     if (sk) atomicAdd(&d.stats[s * 5 + 0], d.basic ? 2 : 1);
                 }
-                const int nq = sk ? 4 : 1, q0 = sk ? 0 : part;
-                if (ln < nq) {
+                const int nw = sk ? 4 : 1, q0 = sk ? 0 : part;
+                if (ln < nw) {
                     __hip_atomic_store(chw + (size_t)mb * 4 + q0 + ln, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     *(int *)(mvs + ((size_t)mb * 4 + q0 + ln) * 2) = r;
                 }
-                PR_MARK(3)
-                __syncthreads();
-                PR_MARK(4)
-                prevw = r;
-                if (part == 0) skip = sk;
-            } else {
-                int k2, xy2, k3, xy3;
-                resolve_local_back<WIN>(d, s, gx, gy, ln, cur, N, loc_lds);
-                __syncthreads();
-                resolve_stage23<WIN>(d, s, gx, gy, ln, cur, N, sel_lds, k2, xy2, k3, xy3);
-#ifdef FER_PROBE
-                if (FER_DBGF(d, 128) && s == 0 && lane == 0) {
-                    const unsigned long long dt = (unsigned long long)(wall_clock64() - tst);
-                    atomicMax((unsigned long long *)&d.timing[41], (dt << 24) | ((unsigned long long)gx << 12) | (unsigned long long)gy);
-                    atomicAdd((unsigned long long *)&d.timing[42], dt);
-                    if (dt > 20000) atomicAdd((unsigned long long *)&d.timing[43], 1ull);  // calls of more than 200 us
-                }
-#endif
-                if (ln == 0) {
-                    xch[0] = k2;
-                    xch[1] = xy2;
-                    xch[2] = k3;
-                    xch[3] = xy3;
-                }
-                PR_MARK(1)
-                __syncthreads();
-                PR_MARK(2)
-                __syncthreads();  // the merged result is in xch[4..5]
-                PR_MARK(4)
-                prevw = xch[4];
-                if (part == 0) skip = xch[5] != 0;
             }
+            PR_MARK(3)
+            prevw = r;
+            if (part == 0) skip = sk;
         }
     }
     if (probe && lane == 0) {
@@ -1782,6 +1938,12 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
     }
 #undef PR_MARK
     if (timeout && lane == 0) atomicOr(&d.status[s], FER_ERR_CHAIN_TIMEOUT);
+    }
+    if (threadIdx.x == 0 && st_parts + st_skq > 0) {
+        atomicAdd(&d.spec_stat[0], (unsigned long long)st_parts);
+        atomicAdd(&d.spec_stat[1], (unsigned long long)st_hits);
+        atomicAdd(&d.spec_stat[2], (unsigned long long)st_skq);
+        atomicAdd(&d.spec_stat[3], (unsigned long long)st_skh);
     }
 }
 
@@ -1850,6 +2012,18 @@ void fer_launch_me_walk(const FerDev &d, hipStream_t st)
 {
     if (d.basic) return;  // stage 2 is not run (F/moestimation.cpp:470)
     hipLaunchKernelGGL(k_me_walk, dim3(d.nmb * 4, d.S), dim3(64), 0, st, d);
+}
+
+void fer_launch_me_spec(const FerDev &d, hipStream_t st)
+{
+    if (!d.speculate) return;
+    dim3 g(d.nmb, d.S);
+    if (d.window == 32)
+        hipLaunchKernelGGL(k_me_spec<32>, g, dim3(256), 0, st, d);
+    else if (d.window == 16)
+        hipLaunchKernelGGL(k_me_spec<16>, g, dim3(256), 0, st, d);
+    else
+        hipLaunchKernelGGL(k_me_spec<0>, g, dim3(256), 0, st, d);
 }
 
 void fer_launch_me_resolve(const FerDev &d, hipStream_t st)

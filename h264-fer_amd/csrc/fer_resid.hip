@@ -83,7 +83,12 @@ __global__ __launch_bounds__(256) void k_p_resid(FerDev d)
         tbl = ((const int *)mvs)[(size_t)iclamp(mb + off, 0, d.nmb - 1) * 4 + q];
     }
     if (ptype != 0) return;
-    if (mtype == FER_P_SKIP) return;  // reconstructed by k_me_resolve
+    // every vector of the macroblock must carry this picture's serial: a row the motion chain never reached (it cannot
+    // happen by construction; ferhip_status bit 6 if it ever does) would otherwise go on with stale vectors silently
+    if (lane < 4) {
+        const unsigned long long w = d.chain64[((size_t)s * d.nmb + mb) * 4 + lane];
+        if (((unsigned)(w >> 32) & 0x7fffffffu) != ((unsigned)d.serial & 0x7fffffffu)) atomicOr(&d.status[s], FER_ERR_CHAIN_UNRESOLVED);
+    }
 
     // ---- partition merge and mvd under the final type (F/moestimation.cpp:529-560); every vector of the
     // picture is final here, so nothing below is read by another macroblock's decision
@@ -119,6 +124,13 @@ __global__ __launch_bounds__(256) void k_p_resid(FerDev d)
         mc_luma4(RY, ip_stream(d, s), W, H, xp, yp, lx, ly, qx, qy, pfL);
         mv_of(cb, qx, qy);
         mc_chroma_row4(Rp, Wc, Hc, xp / 2, yp / 2, cx0, cy0, qx, qy, pfC);
+    }
+    if (mtype == FER_P_SKIP) {
+        // P_Skip (decided by k_me_resolve, which left the P_Skip vector in all four quadrants): the reconstruction is
+        // the prediction (F/moestimation.cpp:421-425, F/inttransform.cpp:215-231)
+        *(uint32_t *)dstL = (uint32_t)pfL[0] | ((uint32_t)pfL[1] << 8) | ((uint32_t)pfL[2] << 16) | ((uint32_t)pfL[3] << 24);
+        if (lane < 32) *(uint32_t *)dstC = (uint32_t)pfC[0] | ((uint32_t)pfC[1] << 8) | ((uint32_t)pfC[2] << 16) | ((uint32_t)pfC[3] << 24);
+        return;
     }
     {
         const int np = type == FER_P_L0_16x16 ? 1 : (type == FER_P_8x8ref0 ? 4 : 2);

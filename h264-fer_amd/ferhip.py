@@ -8,9 +8,11 @@ import numpy as np
 NAL_SLICE, NAL_IDR, NAL_AUTO = 1, 5, 0
 
 BUF = dict(INTERP=1, FEAT=2, SORTPOS=3, KOLIKO=4, MBTYPE=5, MV=6, MVD=7, LEVELS=8, CBP=9, TC=10, I4MODE=11,
-           CUR=12, REF=13, TIMING=14, ST2N=15, ST2=16)
+           CUR=12, REF=13, TIMING=14, ST2N=15, ST2=16, SPEC_STAT=17)
+TUNE_RESOLVE_WGS, TUNE_RESOLVE_GROUP, TUNE_SPECULATE = 1, 2, 3
 _BUF_DTYPE = {1: np.uint8, 2: np.uint16, 3: np.uint32, 4: np.int32, 5: np.int32, 6: np.int16, 7: np.int16,
-              8: np.int16, 9: np.uint8, 10: np.uint8, 11: np.uint8, 12: np.uint8, 13: np.uint8, 14: np.int64, 15: np.int32, 16: np.int32}
+              8: np.int16, 9: np.uint8, 10: np.uint8, 11: np.uint8, 12: np.uint8, 13: np.uint8, 14: np.int64, 15: np.int32, 16: np.int32,
+              17: np.uint64}
 
 
 class FerHipError(RuntimeError):
@@ -255,14 +257,14 @@ class FerHip:
         n = self.nmb * self.S
         px = self.W * self.H * self.S
         count = {1: px * 16, 2: px * 96, 3: px, 4: 16385 * self.S, 5: n, 6: n * 8, 7: n * 8, 8: n * 400, 9: n * 2,
-                 10: n * 24, 11: n * 16, 12: self.fsz * self.S, 13: self.fsz * self.S, 14: 64, 15: n * 4, 16: n * 4 * 384 * 2}[which]
+                 10: n * 24, 11: n * 16, 12: self.fsz * self.S, 13: self.fsz * self.S, 14: 64, 15: n * 4, 16: n * 4 * 384 * 2, 17: 8}[which]
         out = np.empty(count, _BUF_DTYPE[which])
         got = self.lib.ferhip_read_buffer(self.ctx, which, out.ctypes.data, out.nbytes)
         if got != out.nbytes:
             raise FerHipError(f"ferhip_read_buffer({name}) returned {got}, expected {out.nbytes}")
         return out
 
-    PHASES = ("interp", "me_pre", "me_resolve", "p_resid", "intra", "cavlc", "frame_sad", "features", "sort", "me_walk",
+    PHASES = ("interp", "me_pre", "me_resolve", "p_resid", "intra", "cavlc", "frame_sad", "me_spec", "sort", "me_walk",
               "sort_keys", "sort_finish")
     NPHASE = 12
 

@@ -115,7 +115,7 @@ int ferhip_encode_streams(ferhip_ctx *c, const uint8_t *frames, int nframes, uin
 /* statistics of Starter::DohvatiStatistiku: brojTipova[5] per stream, accumulated */
 int ferhip_get_stats(ferhip_ctx *c, int *counts5_per_stream);
 /* sticky device error flags per stream (bits 0, 1: unused, bit 2: RBSP buffer overflow, bits 3, 4: decoder syntax
- * error / unsupported syntax, bit 5: motion chain timeout) */
+ * error / unsupported syntax, bit 5: motion chain timeout, bit 6: a P macroblock without this picture's vectors) */
 int ferhip_status(ferhip_ctx *c, int *flags_per_stream);
 const char *ferhip_version(void);
 
@@ -129,17 +129,19 @@ const char *ferhip_version(void);
 #define FERHIP_PH_INTRA 4      /* k_intra_mb, one launch per MB anti-diagonal */
 #define FERHIP_PH_CAVLC 5      /* size + scan + emit */
 #define FERHIP_PH_FRAME_SAD 6
-#define FERHIP_PH_FEATURES 7   /* k_features: box features of every position and plane */
+#define FERHIP_PH_ME_SPEC 7    /* k_me_spec: the predictor-dependent searches for a guessed predictor */
 #define FERHIP_PH_SORT 8       /* the two radix passes: k_rs_hist, k_rs_scan, k_rs_scatter, each twice */
 #define FERHIP_PH_ME_WALK 9    /* k_me_walk: stage-2 candidate sets */
-#define FERHIP_PH_SORT_KEYS 10   /* k_sort_keys */
-#define FERHIP_PH_SORT_FINISH 11 /* k_sort_finish: payload of the sorted order + bucket index */
+#define FERHIP_PH_SORT_KEYS 10   /* k_feat0: plane-0 features + the sort's input records */
+#define FERHIP_PH_SORT_FINISH 11 /* k_sort_index (+ k_bucket_classes, k_sort_quirk): bucket index of the sorted order */
 #define FERHIP_NPHASE 12
 int ferhip_profile(ferhip_ctx *c, int enable);
 /* launch-shape knobs; results never depend on them.  RESOLVE_WGS = workgroups of the persistent motion-chain launch
- * (default 1536: leaves CU slots to a second context; a context that has the GPU to itself can take more) */
+ * (default 3072; any value >= 1 resolves every row: a workgroup whose own queue is empty takes rows of the others) */
 #define FERHIP_TUNE_RESOLVE_WGS 1
-#define FERHIP_TUNE_RESOLVE_GROUP 2 /* streams whose rows the motion chain keeps in flight together (cache footprint) */
+#define FERHIP_TUNE_RESOLVE_GROUP 2 /* streams whose rows the motion chain keeps in flight together (cache footprint); clamped to the context's streams */
+#define FERHIP_TUNE_SPECULATE 3     /* 1 (default): k_me_spec runs the predictor-dependent searches for a guessed predictor and the
+                                       chain verifies; 0: the chain searches everything itself */
 int ferhip_tune(ferhip_ctx *c, int key, int value);
 int ferhip_get_profile(ferhip_ctx *c, double *ms, long *launches, int reset);
 
@@ -167,6 +169,8 @@ int ferhip_inter_encoding(ferhip_ctx *c);
 #define FERHIP_BUF_REF 13     /* uint8  [S][W*H*3/2] reference picture buffers */
 #define FERHIP_BUF_TIMING 14  /* int64  [64] in-kernel wall-clock sums (10 ns units) when FER_DBG bit 7 is set */
 #define FERHIP_BUF_ST2N 15    /* int32  [S][nmb][4] stage-2 candidates of every 8x8 partition (before the list cap) */
+#define FERHIP_BUF_SPEC_STAT 17 /* uint64 [8] since the context was created: partitions the motion chain decided, of which the guessed
+                                 predictor was right, P_Skip verdicts needed, of which taken from the guess */
 #define FERHIP_BUF_ST2 16     /* int32  [S][nmb][4][384][2] the candidates (position relative to the block, feature distance); a crowded
                                  partition (count > 384) holds its summary instead: [40] = (last step, distance bound), [41] = (zeros, 0) */
 size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t cap);

@@ -53,6 +53,50 @@ def _check_against_oracle(pkg, fo, W, H, T, S, qp, window, intra_every, noise=2,
     return frames, streams, rec
 
 
+_ORACLE_CACHE = {}
+
+
+def _oracle_stream(fo, frames, key, W, H, **kw):
+    if key not in _ORACLE_CACHE:
+        o = fo.Oracle(W, H, **kw)
+        ref, ref_rec = o.encode_stream(frames)
+        cnt = [int(v) for v in o.stats()]
+        o.close()
+        _ORACLE_CACHE[key] = (ref, ref_rec, cnt)
+    return _ORACLE_CACHE[key]
+
+
+@pytest.mark.parametrize("S,window,wgs,group,spec", [(17, 16, 1, 4, 1), (17, 32, 3, 4, 1), (24, 16, 7, 1, 1), (24, 32, 8, 3, 1),
+                                                      (24, 16, 64, 4, 0), (24, 32, 3072, 100, 1), (17, 32, 3, 2, 0)])
+def test_many_streams_take_the_per_xcd_queues(pkg, fo, S, window, wgs, group, spec):
+    """S >= 16 switches the motion chain to its eight ticket queues (one per XCD; what bench.py runs).  Every stream is
+    compared with the oracle -- bitstream, reconstruction, brojTipova -- under launch shapes that cannot cover the eight
+    XCDs (1, 3, 7 workgroups: rows are then taken by workgroups that move from queue to queue), with short last stream
+    groups, and with the speculative pre-pass on and off.  Every fifth stream is a still sequence (P_Skip macroblocks)."""
+    W, H, T = 176, 144, 4
+    def src(s, t):
+        return pkg.gen_frame(W, H, 0 if s % 5 == 4 else t, 1234 + s, 0 if s % 5 == 4 else 2)
+    frames = np.stack([np.stack([src(s, t) for s in range(S)]) for t in range(T)])
+    g = pkg.FerHip(W, H, S, qp=12, window=window, maxdiff=3, intra_every=30)
+    g.tune(pkg.TUNE_RESOLVE_WGS, wgs)
+    g.tune(pkg.TUNE_RESOLVE_GROUP, group)
+    g.tune(pkg.TUNE_SPECULATE, spec)
+    streams, rec = g.encode_streams(frames, want_recon=True)
+    assert g.status() == [0] * S
+    counts = g.stats()
+    st = g.read("SPEC_STAT")
+    g.close()
+    for s in range(S):
+        ref, ref_rec, ref_counts = _oracle_stream(fo, frames[:, s], (s, window), W=W, H=H, qp=12, window=window, maxdiff=3, intra_every=30)
+        assert streams[s] == ref, f"bitstream of stream {s}"
+        assert np.array_equal(rec[:, s], ref_rec), f"recon of stream {s}"
+        assert [int(v) for v in counts[s]] == ref_counts, f"brojTipova of stream {s}"
+    assert counts[4][0] > 0, "the still streams are meant to contain P_Skip macroblocks"
+    parts, hits, skq, skh = (int(v) for v in st[:4])
+    assert parts > 0 and hits <= parts and skh <= skq and skq == S * (T - 1) * (W // 16) * (H // 16)
+    assert (hits > 0) == bool(spec)
+
+
 def test_720p_intra_config(pkg, fo):
     """BASELINE configs[1]: 720p I-frame encode (4x4 transform + quant + CAVLC), bit-exact."""
     _check_against_oracle(pkg, fo, 1280, 720, 2, 2, qp=12, window=16, intra_every=1, check_streams=(0, 1))
