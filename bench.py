@@ -55,6 +55,7 @@ KERNELS = {
     "sort_finish": ("k_sort_index+k_bucket_classes+k_sort_quirk", 256 * 6 + 1956, "hbm", "P"),
     "me_pre": ("k_me_pre", ME_BYTES_PER_MB, "valu", "P"),
     "me_walk": ("k_me_walk", ME_BYTES_PER_MB, "valu", "P"),
+    "me_spec": ("k_me_spec", ME_BYTES_PER_MB, "valu", "P"),
     "me_resolve": ("k_me_resolve", ME_BYTES_PER_MB, "valu", "P"),
     "p_resid": ("k_p_resid", 1152, "hbm", "P"),
     "intra": ("k_intra_mb", 768, "latency", "I"),
@@ -135,6 +136,7 @@ def main():
     ap.add_argument("--probe-build", type=int, default=0, help="development only: a -DFER_PROBE library with FER_DBG set skips "
                     "stages on purpose, so a wrong output hash is reported (\"ok\": false) instead of ending the run")
     ap.add_argument("--resolve-wgs", type=int, default=0, help="workgroups of the persistent motion-chain launch (0 = library default)")
+    ap.add_argument("--speculate", type=int, default=1, help="0 = the motion chain searches everything itself (no k_me_spec pre-pass)")
     ap.add_argument("--resolve-group", type=int, default=0, help="streams per ticket group of the motion chain (0 = library default)")
     ap.add_argument("--dist-backend", default=os.environ.get("FER_BENCH_BACKEND", "nccl"),
                     help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal: several ranks may share GPU 0)")
@@ -216,9 +218,10 @@ def main():
     for e in encs:
         # the persistent motion-chain launch of a context takes its share of the GPU's workgroup slots: with two
         # contexts each leaves room for the other's streaming kernels
-        e.tune(1, args.resolve_wgs or (3072 if NC == 1 else max(768, min(3072, 24 * e.S))))  # two contexts share the workgroup slots; measured: 64 streams -> 1536, 128 and more -> 3072
+        e.tune(1, args.resolve_wgs or (6144 if NC == 1 else max(1536, min(6144, 48 * e.S))))  # two contexts share the workgroup slots; measured: 64 streams -> 1536, 128 and more -> 3072
         if args.resolve_group:
             e.tune(2, args.resolve_group)
+        e.tune(3, args.speculate)
 
     def run_ctx(i, sink=None):
         e, fr = encs[i], parts[i]
@@ -258,6 +261,7 @@ def main():
     for _ in range(args.warmup):
         step()
     stats0 = [e.stats().copy() for e in encs]
+    spec0 = [e.read("SPEC_STAT").copy() for e in encs]
     for e in encs:
         e.get_profile(reset=True)
         e.profile(True)
@@ -282,6 +286,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     counts = sum((e.stats() - s0).sum(axis=0) for e, s0 in zip(encs, stats0))   # brojTipova over the timed steps
+    spec = sum((e.read("SPEC_STAT") - s0).astype("int64") for e, s0 in zip(encs, spec0))
 
     total_mbs = total_streams * GOP * nmb * args.steps
     value = total_mbs / dt
@@ -444,6 +449,9 @@ def main():
                "skip_fraction": round(float(counts[0]) / coded, 6) if coded else None,
                "mb_types": {"p_skip": int(counts[0]), "p16x16": int(counts[1]), "p16x8": int(counts[2]),
                             "p8x16": int(counts[3]), "p8x8": int(counts[4])},
+               "speculation": {"partitions_decided_by_chain": int(spec[0]), "predictor_guess_hits": int(spec[1]),
+                               "hit_rate": round(float(spec[1]) / max(int(spec[0]), 1), 5),
+                               "pskip_verdicts": int(spec[2]), "pskip_guess_hits": int(spec[3])},
                "output_check": check, "secondary": secondary}
         print(json.dumps(out), flush=True)
     for e in encs:

@@ -204,7 +204,7 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
 #endif
     d.ysz = (size_t)W * H;
     d.csz = d.ysz / 4;
-    d.resolve_wgs = 3072;
+    d.resolve_wgs = 6144;
     d.resolve_group = 4;
     {
         int lo = 0, hi = 0;  // numerically lower = higher priority

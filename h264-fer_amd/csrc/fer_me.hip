@@ -1253,25 +1253,6 @@ __device__ __forceinline__ void wave_best(int best, int bestxy, int &wkey, int &
     if (wkey != 0x7fffffff) wxy = lane_bcast(bestxy, __ffsll((long long)__ballot(best == wkey)) - 1);
 }
 
-// The chain's own search (after a wrong guess).  The on-chip features of stage 1's local search are built by BOTH
-// wavefronts of the workgroup, 8 planes each (their own row-sum tables, one table of metrics: resolve_local_half); a
-// workgroup barrier later wavefront 0 selects and refines (resolve_stage1_rest) while wavefront 1 runs stages 2 and 3.
-#define RES_HTAB LocalGeo<2>::HTAB
-template <int WIN>
-__device__ __forceinline__ void resolve_local_half(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, int genx, int geny,
-                                                   uint32_t *loc_lds, int half)
-{
-    if (FER_DBGF(d, 16)) return;
-    if (WIN == 32 || WIN == 16) {
-        constexpr int RR = (WIN ? WIN : 32) / 16;
-        const int window = WIN ? WIN : d.window;
-        const int r1 = window / 16;
-        const SuPk sp = su_pack(P.su);
-        local_metrics<RR>(ip_stream(d, s), d.W, d.H, gx * 8 + genx - r1, gy * 8 + geny - r1, sp, lane, loc_lds + half * RES_HTAB,
-                          (int *)loc_lds + 2 * RES_HTAB, half, half + 1);
-    }
-}
-
 // ---- P_Skip (F/mode_pred.cpp:381-402 + F/moestimation.cpp:402-425) ----
 // the vector of the P_Skip candidate: the 16x16 predictor, or zero at the picture's top / left edge and next to a zero
 // neighbour
@@ -1359,15 +1340,20 @@ __device__ __forceinline__ int stage1_list(const FerDev &d, int s, int gx, int g
     return __popcll(__ballot(lane < 17 && L1.m < 100000000));
 }
 
-// role 0 of the chain's own search, after the barrier: stage 1 proper -> the best (key, vector)
+// the chain's own search (after a wrong guess), stage 1: the local features, the list, its SADs -> the best (key, vector)
 template <int WIN>
-__device__ __forceinline__ void resolve_stage1_rest(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, int mvpx, int mvpy,
-                                                    int *sel_lds, uint32_t *loc_lds, int &wkey, int &wxy)
+__device__ __forceinline__ void resolve_stage1(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, int mvpx, int mvpy,
+                                               uint32_t *htab, int *mtab, int &wkey, int &wxy)
 {
     wkey = 0x7fffffff;
     wxy = 0;
+    if (FER_DBGF(d, 16)) return;
+    if (WIN == 32 || WIN == 16) {
+        constexpr int RR = (WIN ? WIN : 32) / 16;
+        local_metrics<RR>(ip_stream(d, s), d.W, d.H, gx * 8 + (mvpx >> 2) - RR, gy * 8 + (mvpy >> 2) - RR, su_pack(P.su), lane, htab, mtab);
+    }
     WList L1;
-    const int cnt1 = stage1_list<WIN>(d, s, gx, gy, lane, P, mvpx >> 2, mvpy >> 2, sel_lds, (const int *)loc_lds + 2 * RES_HTAB, L1);
+    const int cnt1 = stage1_list<WIN>(d, s, gx, gy, lane, P, mvpx >> 2, mvpy >> 2, (int *)htab, mtab, L1);  // (the row sums are dead: the selection's scratch)
     if (FER_DBGF(d, 16)) return;
     int b1, b1xy;
     sad_keys<17>(L1, cnt1, lane, ip_stream(d, s), d.W, d.H, gx * 8, gy * 8, P.sb, mvpx, mvpy, b1, b1xy);
@@ -1564,7 +1550,7 @@ __device__ __forceinline__ int stage2_list(const FerDev &d, int s, int gx, int g
     return __popcll(__ballot(lane < 33 && L2.m < 100000000));
 }
 
-// role 1 of the chain's own search: stage 2 and stage 3 (precomputed survivors): best (key, vector) of each
+// the chain's own search, stage 2 and stage 3 (precomputed survivors): best (key, vector) of each
 template <int WIN>
 __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, int gy, int lane, const ResPre &P, int mvpx, int mvpy,
                                                 int *sel_lds, int &k2, int &xy2, int &k3, int &xy3)
@@ -1685,26 +1671,49 @@ __global__ __launch_bounds__(256) void k_me_spec(FerDev d)
     if (lane == 0) d.spec_hdr[pidx] = make_int4(genw, cnt1 | (cnt2 << 8) | (1 << 16) | (part == 0 ? (1 << 17) : 0), smw, 0);
 }
 
-template <int WIN>
-__global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
+__device__ __forceinline__ void res_spec_load(const FerDev &d, bool spec, size_t pidx, int ln, int4 &sh, int2 &e1, int2 &e2, int &c3x, int &c3y,
+                                              int &c3s, int &n3)
 {
-    __shared__ __attribute__((aligned(16))) int sel_all[2][256];
-    __shared__ __attribute__((aligned(16))) uint32_t loc_lds[2 * LocalGeo<2>::HTAB + LocalGeo<2>::NB * 64];  // stage 1's local search: row sums of either wavefront, metrics
-    __shared__ int xch[8];
-    const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int *sel_lds = sel_all[role];
+    sh = make_int4(0, 0, 0, 0);
+    e1 = e2 = make_int2(0, 0);
+    c3x = c3y = c3s = n3 = 0;
+    if (FER_DBGF(d, 512)) pidx &= 1023;  // (probe: the chain with its list reads served from cache)
+    if (spec) {
+        sh = d.spec_hdr[pidx];
+        e1 = d.spec_l1[pidx * 17 + min(ln, 16)];
+        e2 = d.spec_l2[pidx * 33 + min(ln, 32)];
+        if (!d.basic) {
+            const int *c3 = d.st3 + (pidx * 33 + min(ln, 32)) * 3;
+            c3x = c3[0];
+            c3y = c3[1];
+            c3s = c3[2];
+            n3 = d.st3n[pidx];
+        }
+    }
+}
+
+#ifndef RES_WIN
+#define RES_WIN 16  // steps between two loads of the window over the row above (a power of two, RES_WIN + 3 <= 64)
+#endif
+#ifndef RES_WAVES
+#define RES_WAVES 6  // wavefronts per SIMD the chain kernel is compiled for
+#endif
+// ONE WAVEFRONT PER ROW.  With the guessed lists in place a step of the chain is a few hundred instructions, and with
+// thousands of rows in flight the launch is bound by how many instructions it issues, not by the latency of a row: a
+// second wavefront per row (which the chain's own search used to be split over) would only repeat them.
+template <int WIN>
+__global__ __launch_bounds__(64, RES_WAVES) void k_me_resolve(FerDev d)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t loc_lds[LocalGeo<2>::HTAB + LocalGeo<2>::NB * 64];  // the chain's own search: row sums / selection scratch, metrics
+    const int lane = threadIdx.x;
     const int gw = d.mbw * 2, gh = d.mbh * 2;
-    // Row tickets: rows of all streams in row-major order.  The launch is capped at a share of the GPU's
-    // workgroup slots (other contexts' kernels keep finding free slots); a workgroup that finishes a row takes
-    // the next ticket.
-    // One ticket queue per XCD (when there are enough streams): stream s belongs to queue s % 8, and a queue hands out
-    // its streams `resolve_group` at a time, row-major inside the group.  A workgroup starts on the queue of the XCD it
-    // runs on (HW_REG_XCC_ID), so all rows of a stream normally run on ONE XCD: what a partition reads was fetched into that
-    // XCD's L2 by the row above a few steps earlier.  When its queue is exhausted the workgroup moves on to the next
-    // queue: every row is taken whatever the placement of the workgroups (a grid smaller than 8, a CU mask, a partition
-    // mode), and the tail of a picture is shared.  Tickets of one queue are taken in order, so the row a workgroup waits
-    // on was claimed before its own by a workgroup that is running or finished: every wait terminates.
+    // Row tickets.  One ticket queue per XCD (when there are enough streams): stream s belongs to queue s % 8, and a queue
+    // hands out its streams `resolve_group` at a time, row-major inside the group.  A workgroup starts on the queue of the
+    // XCD it runs on (HW_REG_XCC_ID), so all rows of a stream normally run on ONE XCD: what a partition reads was fetched
+    // into that XCD's L2 by the row above a few steps earlier.  When its queue is exhausted the workgroup moves on to the
+    // next queue: every row is taken whatever the placement of the workgroups (a grid smaller than 8, a CU mask, a
+    // partition mode), and the tail of a picture is shared.  Tickets of one queue are taken in order, so the row a
+    // workgroup waits on was claimed before its own by a workgroup that is running or finished: every wait terminates.
     int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     const int nq = d.S >= 16 ? 8 : 1;                 // queues
@@ -1713,13 +1722,11 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
     const bool spec = d.speculate != 0;
     unsigned st_parts = 0, st_hits = 0, st_skq = 0, st_skh = 0;
     for (;;) {
-    __syncthreads();
     const int qu = (q_own + q_done) & (nq - 1);
     const int nsq = (d.S - qu + nq - 1) / nq;         // streams qu, qu + nq, ... of the queue
-    if (threadIdx.x == 0) xch[0] = atomicAdd(d.chain + qu, 1);
-    __syncthreads();
-    const int t = xch[0];
-    __syncthreads();
+    int t = 0;
+    if (lane == 0) t = atomicAdd(d.chain + qu, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
     const int G = d.resolve_group;
     const int grp = t / (gh * G), rr = t - grp * (gh * G);
     const int k0 = grp * G, kn = min(G, nsq - k0);  // streams of this group, as indices into the queue's stream list
@@ -1750,6 +1757,8 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
     long long tacc[6] = {0, 0, 0, 0, 0, 0}, tmark = 0;
     int prevw = 0;  // vector of the previous partition of this row (the left neighbour A)
     bool skip = false, timeout = false;
+    unsigned cwl = 0, cwh = 0;  // the window over the row above: lane l = partition wbase + l
+    int wbase = 0;
     for (int gx = 0; gx < gw; gx++) {
         if (probe) tmark = wall_clock64();
         const int part = (gy & 1) * 2 + (gx & 1);
@@ -1760,22 +1769,24 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
         // are hoisted out of the loop and spilled
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        // what the guessed search left behind, requested before the neighbours are polled (both round trips overlap):
-        // the lane's entry of either list and of the stage-3 survivors
-        int4 sh = make_int4(0, 0, 0, 0);
-        int2 e1 = make_int2(0, 0), e2 = make_int2(0, 0);
-        int c3x = 0, c3y = 0, c3s = 0, n3 = 0;
-        if (spec) {
-            sh = d.spec_hdr[pidx];
-            e1 = d.spec_l1[pidx * 17 + min(ln, 16)];
-            e2 = d.spec_l2[pidx * 33 + min(ln, 32)];
-            if (!d.basic) {
-                const int *c3 = d.st3 + (pidx * 33 + min(ln, 32)) * 3;
-                c3x = c3[0];
-                c3y = c3[1];
-                c3s = c3[2];
-                n3 = d.st3n[pidx];
-            }
+        // what the guessed search left behind: the lane's entry of either list and of the stage-3 survivors
+        int4 sh;
+        int2 e1, e2;
+        int c3x, c3y, c3s, n3;
+        res_spec_load(d, spec, pidx, ln, sh, e1, e2, c3x, c3y, c3s, n3);
+        // A window over the row above: every RES_WIN steps ONE 64-lane load fetches the words of the partitions gx - 1 ...
+        // gx + 62 of that row; the four a step needs come out of it with two ds_bpermute.  A word that was not valid when
+        // the window was loaded (the row above was not that far ahead) is polled for.  (Agent-scope loads cross the
+        // fabric -- the XCDs' L2s are not coherent --: one per sixteen steps instead of one per step.)
+        if ((gx & (RES_WIN - 1)) == 0) {
+            wbase = gx - 1;
+            const int xa = wbase + ln;
+            unsigned long long w = 0;
+            if (gy > 0 && xa >= 0 && xa < gw)
+                w = __hip_atomic_load(chw + ((size_t)(((gy - 1) >> 1) * d.mbw + (xa >> 1)) * 4 + (((gy - 1) & 1) * 2 + (xa & 1))), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+            cwl = (unsigned)w;
+            cwh = (unsigned)(w >> 32);
         }
         // neighbours in the row above: lane 0 = B, 1 = C, 2 = D, 3 = C of the 16x16 (P_Skip) predictor
         const int x = (part & 1) * 8, y = (part >> 1) * 8;
@@ -1786,10 +1797,11 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
             int ny = ln == 3 ? -1 : y - 1;
             nbr_locate_xy(d.mbw, mbx, mby, nx, ny, val, mbN, q);
         }
-        unsigned wl = 0, wh = 0;
-        for (int it = 0;; it++) {
-            bool ok = true;
-            if (val) {
+        const int widx = gx - wbase + (ln == 0 ? 0 : (ln == 1 ? 1 : (ln == 2 ? -1 : 2)));  // B, C, D, C16 sit at gx, gx + 1, gx - 1, gx + 2
+        unsigned wl = (unsigned)__shfl((int)cwl, widx & 63), wh = (unsigned)__shfl((int)cwh, widx & 63);
+        bool ok = !val || (wh & 0x7fffffffu) == serial;
+        for (int it = 0; !__all(ok); it++) {
+            if (val && !ok) {
                 unsigned long long w = __hip_atomic_load(chw + (size_t)mbN * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 wl = (unsigned)w;
                 wh = (unsigned)(w >> 32);
@@ -1820,9 +1832,6 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
             if (skip) prevw = N.B;
         }
         if (part == 0 || !skip) {
-            // Both wavefronts of the workgroup hold the same neighbours and come to the same decisions: P_Skip and the
-            // pricing of the guessed lists are evaluated by both (no barrier on the common path); only the chain's own
-            // search, after a wrong guess, splits the work and meets at barriers -- which both reach or both do not.
             bool sk = false;
             int r = 0;
             if (part == 0) {  // ---- P_Skip candidate
@@ -1830,8 +1839,8 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
                 pskip_vector(d, mb, mbx, N, smx, smy);
                 r = pack_xy(smx, smy);
                 st_skq++;
-                if (((sh.y >> 17) & 1) && sh.z == r) {
-                    sk = sh.w != 0;
+                if ((((sh.y >> 17) & 1) && sh.z == r) || FER_DBGF(d, 512)) {
+                    sk = sh.w != 0 && !FER_DBGF(d, 512);
                     st_skh++;
                 } else {
                     sk = pskip_test(d, s, mbx, mby, ln, smx, smy);
@@ -1841,7 +1850,7 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
                 int mvpx, mvpy;
                 predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
                 st_parts++;
-                if (((sh.y >> 16) & 1) && sh.x == pack_xy(mvpx >> 2, mvpy >> 2)) {
+                if ((((sh.y >> 16) & 1) && sh.x == pack_xy(mvpx >> 2, mvpy >> 2)) || FER_DBGF(d, 512)) {
                     // ---- the guess was right: cost = SAD + |mv - mvp| over the three lists; the reference's ordered
                     // first minimum (stage 1, 2, 3 in turn, strict <, F/moestimation.cpp:460-520) is the minimum of
                     // cost << 8 | stage << 6 | list index
@@ -1869,63 +1878,40 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
                     int wkey;
                     wave_best(key, kxy, wkey, r);
                 } else {
-                    // ---- the chain's own search: wavefront 0 stage 1, wavefront 1 stages 2 and 3
+                    // ---- the chain's own search: stage 1, then stages 2 and 3
                     ResPre cur;
-                    res_prefetch(d, s, gx, gy, ln, role, cur);
-                    resolve_local_half<WIN>(d, s, gx, gy, ln, cur, mvpx >> 2, mvpy >> 2, loc_lds, role);
-                    __syncthreads();  // both halves of the local features are in place
-                    if (role == 0) {
-                        int k1, xy1;
-                        resolve_stage1_rest<WIN>(d, s, gx, gy, ln, cur, mvpx, mvpy, sel_lds, loc_lds, k1, xy1);
-                        PR_MARK(1)
-                        __syncthreads();  // stage 2/3 results are in xch[0..3]
-                        PR_MARK(2)
-                        int bmin = 2000000000;  // ordered first minimum over stage 1, 2, 3 (strict <)
-                        r = 0;
-                        if (k1 != 0x7fffffff && (k1 >> 6) < bmin) {
-                            bmin = k1 >> 6;
-                            r = xy1;
-                        }
-                        const int k2 = xch[0], k3 = xch[2];
-                        if (k2 != 0x7fffffff && (k2 >> 6) < bmin) {
-                            bmin = k2 >> 6;
-                            r = xch[1];
-                        }
-                        if (k3 != 0x7fffffff && (k3 >> 6) < bmin) {
-                            bmin = k3 >> 6;
-                            r = xch[3];
-                        }
-                        if (ln == 0) xch[4] = r;
-                        __syncthreads();
-                    } else {
-                        int k2, xy2, k3, xy3;
-                        resolve_stage23<WIN>(d, s, gx, gy, ln, cur, mvpx, mvpy, sel_lds, k2, xy2, k3, xy3);
-                        if (ln == 0) {
-                            xch[0] = k2;
-                            xch[1] = xy2;
-                            xch[2] = k3;
-                            xch[3] = xy3;
-                        }
-                        PR_MARK(1)
-                        __syncthreads();
-                        PR_MARK(2)
-                        __syncthreads();  // the merged result is in xch[4]
-                        r = xch[4];
+                    res_prefetch(d, s, gx, gy, ln, 1, cur);
+                    int k1, xy1, k2, xy2, k3, xy3;
+                    resolve_stage1<WIN>(d, s, gx, gy, ln, cur, mvpx, mvpy, loc_lds, (int *)loc_lds + LocalGeo<2>::HTAB, k1, xy1);
+                    PR_MARK(1)
+                    resolve_stage23<WIN>(d, s, gx, gy, ln, cur, mvpx, mvpy, (int *)loc_lds, k2, xy2, k3, xy3);
+                    PR_MARK(2)
+                    int bmin = 2000000000;  // ordered first minimum over stage 1, 2, 3 (strict <)
+                    r = 0;
+                    if (k1 != 0x7fffffff && (k1 >> 6) < bmin) {
+                        bmin = k1 >> 6;
+                        r = xy1;
+                    }
+                    if (k2 != 0x7fffffff && (k2 >> 6) < bmin) {
+                        bmin = k2 >> 6;
+                        r = xy2;
+                    }
+                    if (k3 != 0x7fffffff && (k3 >> 6) < bmin) {
+                        bmin = k3 >> 6;
+                        r = xy3;
                     }
                 }
             }
-            if (role == 0) {
-                const unsigned long long w = (unsigned)r | ((unsigned long long)(serial | (sk ? CH_SKIP : 0u)) << 32);
-                if (part == 0 && ln == 0) {
-                    mbt[mb] = sk ? FER_P_SKIP : FER_P_8x8ref0;  // also clears a P_Skip left by the previous picture
-                    // BasicInterEncoding makes the P_Skip test twice and counts it twice (F/moestimation.cpp:324,421)
-                    if (sk) atomicAdd(&d.stats[s * 5 + 0], d.basic ? 2 : 1);
-                }
-                const int nw = sk ? 4 : 1, q0 = sk ? 0 : part;
-                if (ln < nw) {
-                    __hip_atomic_store(chw + (size_t)mb * 4 + q0 + ln, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *(int *)(mvs + ((size_t)mb * 4 + q0 + ln) * 2) = r;
-                }
+            const unsigned long long w = (unsigned)r | ((unsigned long long)(serial | (sk ? CH_SKIP : 0u)) << 32);
+            if (part == 0 && ln == 0) {
+                mbt[mb] = sk ? FER_P_SKIP : FER_P_8x8ref0;  // also clears a P_Skip left by the previous picture
+                // BasicInterEncoding makes the P_Skip test twice and counts it twice (F/moestimation.cpp:324,421)
+                if (sk) atomicAdd(&d.stats[s * 5 + 0], d.basic ? 2 : 1);
+            }
+            const int nw = sk ? 4 : 1, q0 = sk ? 0 : part;
+            if (ln < nw) {
+                __hip_atomic_store(chw + (size_t)mb * 4 + q0 + ln, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *(int *)(mvs + ((size_t)mb * 4 + q0 + ln) * 2) = r;
             }
             PR_MARK(3)
             prevw = r;
@@ -1933,13 +1919,13 @@ __global__ __launch_bounds__(128, 6) void k_me_resolve(FerDev d)
         }
     }
     if (probe && lane == 0) {
-        for (int k = 0; k < 6; k++) d.timing[role * 8 + k] = tacc[k];
-        d.timing[role * 8 + 7] = gw;
+        for (int k = 0; k < 6; k++) d.timing[k] = tacc[k];
+        d.timing[7] = gw;
     }
 #undef PR_MARK
     if (timeout && lane == 0) atomicOr(&d.status[s], FER_ERR_CHAIN_TIMEOUT);
     }
-    if (threadIdx.x == 0 && st_parts + st_skq > 0) {
+    if (lane == 0 && st_parts + st_skq > 0) {
         atomicAdd(&d.spec_stat[0], (unsigned long long)st_parts);
         atomicAdd(&d.spec_stat[1], (unsigned long long)st_hits);
         atomicAdd(&d.spec_stat[2], (unsigned long long)st_skq);
@@ -2033,9 +2019,9 @@ void fer_launch_me_resolve(const FerDev &d, hipStream_t st)
     const int cap = d.resolve_wgs;
     dim3 g(min(gh * d.S, max(cap, 1)));
     if (d.window == 32)
-        hipLaunchKernelGGL(k_me_resolve<32>, g, dim3(128), 0, st, d);
+        hipLaunchKernelGGL(k_me_resolve<32>, g, dim3(64), 0, st, d);
     else if (d.window == 16)
-        hipLaunchKernelGGL(k_me_resolve<16>, g, dim3(128), 0, st, d);
+        hipLaunchKernelGGL(k_me_resolve<16>, g, dim3(64), 0, st, d);
     else
-        hipLaunchKernelGGL(k_me_resolve<0>, g, dim3(128), 0, st, d);
+        hipLaunchKernelGGL(k_me_resolve<0>, g, dim3(64), 0, st, d);
 }

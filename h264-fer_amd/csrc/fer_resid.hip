@@ -82,13 +82,14 @@ __global__ __launch_bounds__(256) void k_p_resid(FerDev d)
         const int off = which == 0 ? 0 : (which == 1 ? -1 : (which == 2 ? -d.mbw : (which == 3 ? 1 - d.mbw : -1 - d.mbw)));
         tbl = ((const int *)mvs)[(size_t)iclamp(mb + off, 0, d.nmb - 1) * 4 + q];
     }
-    if (ptype != 0) return;
     // every vector of the macroblock must carry this picture's serial: a row the motion chain never reached (it cannot
-    // happen by construction; ferhip_status bit 6 if it ever does) would otherwise go on with stale vectors silently
-    if (lane < 4) {
-        const unsigned long long w = d.chain64[((size_t)s * d.nmb + mb) * 4 + lane];
-        if (((unsigned)(w >> 32) & 0x7fffffffu) != ((unsigned)d.serial & 0x7fffffffu)) atomicOr(&d.status[s], FER_ERR_CHAIN_UNRESOLVED);
-    }
+    // happen by construction; ferhip_status bit 6 if it ever does) would otherwise go on with stale vectors silently.
+    // Requested here with everything else, tested when the macroblock is done.
+    const unsigned chw_hi = (unsigned)(d.chain64[((size_t)s * d.nmb + mb) * 4 + (lane & 3)] >> 32);
+    auto chain_check = [&]() {
+        if (lane < 4 && (chw_hi & 0x7fffffffu) != ((unsigned)d.serial & 0x7fffffffu)) atomicOr(&d.status[s], FER_ERR_CHAIN_UNRESOLVED);
+    };
+    if (ptype != 0) return;
 
     // ---- partition merge and mvd under the final type (F/moestimation.cpp:529-560); every vector of the
     // picture is final here, so nothing below is read by another macroblock's decision
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void k_p_resid(FerDev d)
         // the prediction (F/moestimation.cpp:421-425, F/inttransform.cpp:215-231)
         *(uint32_t *)dstL = (uint32_t)pfL[0] | ((uint32_t)pfL[1] << 8) | ((uint32_t)pfL[2] << 16) | ((uint32_t)pfL[3] << 24);
         if (lane < 32) *(uint32_t *)dstC = (uint32_t)pfC[0] | ((uint32_t)pfC[1] << 8) | ((uint32_t)pfC[2] << 16) | ((uint32_t)pfC[3] << 24);
+        chain_check();
         return;
     }
     {
@@ -262,6 +264,7 @@ __global__ __launch_bounds__(256) void k_p_resid(FerDev d)
         d.cbp[((size_t)s * d.nmb + mb) * 2] = (uint8_t)l;
         d.cbp[((size_t)s * d.nmb + mb) * 2 + 1] = (uint8_t)ch;
     }
+    chain_check();
 }
 
 void fer_launch_p_resid(const FerDev &d, hipStream_t st)

@@ -137,7 +137,7 @@ const char *ferhip_version(void);
 #define FERHIP_NPHASE 12
 int ferhip_profile(ferhip_ctx *c, int enable);
 /* launch-shape knobs; results never depend on them.  RESOLVE_WGS = workgroups of the persistent motion-chain launch
- * (default 3072; any value >= 1 resolves every row: a workgroup whose own queue is empty takes rows of the others) */
+ * (default 6144 single-wavefront workgroups; any value >= 1 resolves every row: a workgroup whose own queue is empty takes rows of the others) */
 #define FERHIP_TUNE_RESOLVE_WGS 1
 #define FERHIP_TUNE_RESOLVE_GROUP 2 /* streams whose rows the motion chain keeps in flight together (cache footprint); clamped to the context's streams */
 #define FERHIP_TUNE_SPECULATE 3     /* 1 (default): k_me_spec runs the predictor-dependent searches for a guessed predictor and the
