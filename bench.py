@@ -47,20 +47,22 @@ CONFIGS = {
                         "(BASELINE configs[3])"),
 }
 
-# phase -> (kernel, algorithmic bytes per macroblock, limiter, runs on "P" / "I" / "all" pictures)
+# phase -> (kernel, algorithmic bytes per macroblock, runs on "P" / "I" / "all" pictures).  What limits a
+# kernel is not stated here: it is read from the counters of the last profiling pass (profiles/r03_traffic.json, "limiter":
+# HBM bytes per second against the 6.29 TB/s a copy reaches, VALU / scalar instructions against their issue rates).
 KERNELS = {
-    "interp": ("k_interp", 256 + 16 * 256, "hbm", "P"),
-    "sort_keys": ("k_feat0", 256 + 256 * (12 + 16 + 2), "hbm", "P"),
-    "sort": ("k_rs_hist+k_rs_scan+k_rs_scatter (two radix passes)", 256 * (2 + 1 + 2 + 16 + 16 + 1 + 1 + 16 + 12 + 4 + 2), "hbm", "P"),
-    "sort_finish": ("k_sort_index+k_bucket_classes+k_sort_quirk", 256 * 6 + 1956, "hbm", "P"),
-    "me_pre": ("k_me_pre", ME_BYTES_PER_MB, "valu", "P"),
-    "me_walk": ("k_me_walk", ME_BYTES_PER_MB, "valu", "P"),
-    "me_spec": ("k_me_spec", ME_BYTES_PER_MB, "valu", "P"),
-    "me_resolve": ("k_me_resolve", ME_BYTES_PER_MB, "valu", "P"),
-    "p_resid": ("k_p_resid", 1152, "hbm", "P"),
-    "intra": ("k_intra_mb", 768, "latency", "I"),
-    "cavlc": ("k_cavlc", 800, "hbm", "all"),
-    "frame_sad": ("k_frame_sad", 512, "hbm", "P"),
+    "interp": ("k_interp", 256 + 16 * 256, "P"),
+    "sort_keys": ("k_feat0", 256 + 256 * (12 + 16 + 2), "P"),
+    "sort": ("k_rs_hist+k_rs_scan+k_rs_scatter (two radix passes)", 256 * (2 + 1 + 2 + 16 + 16 + 1 + 1 + 16 + 12 + 4 + 2), "P"),
+    "sort_finish": ("k_sort_index+k_bucket_classes+k_sort_quirk", 256 * 6 + 1956, "P"),
+    "me_pre": ("k_me_pre", ME_BYTES_PER_MB, "P"),
+    "me_walk": ("k_me_walk", ME_BYTES_PER_MB, "P"),
+    "me_spec": ("k_me_spec", ME_BYTES_PER_MB, "P"),
+    "me_resolve": ("k_me_resolve", ME_BYTES_PER_MB, "P"),
+    "p_resid": ("k_p_resid", 1152, "P"),
+    "intra": ("k_intra_mb", 768, "I"),
+    "cavlc": ("k_cavlc", 800, "all"),
+    "frame_sad": ("k_frame_sad", 512, "P"),
 }
 
 
@@ -95,22 +97,29 @@ def spawn_ranks(args, argv):
     print(line, flush=True)
 
 
-def run_oracle_enc(cfg, frames_np, nframes, tag):
-    """oracle/fo_cli (a bit-exact port of the reference, kind 'port') on `nframes` pictures: one process = one core."""
+def stage_oracle_input(frames_np, nframes, tag):
+    """the input file of one fo_cli process, written BEFORE any clock starts"""
+    tmp = Path(os.environ.get("TMPDIR", "/tmp")) / f"ferbench_{os.getpid()}_{tag}"
+    tmp.mkdir(parents=True, exist_ok=True)
+    frames_np[:nframes].tofile(tmp / "in.yuv")
+    return tmp
+
+
+def run_oracle_enc(cfg, tmp, nframes):
+    """oracle/fo_cli (a bit-exact port of the reference, kind 'port') on `nframes` pictures: one process = one core.
+    fo_cli times the encode itself (input read and output written outside its clock)."""
     cli = ROOT / "oracle" / "fo_cli"
     if not cli.exists():
         subprocess.run(["make", "-s", "-C", str(ROOT / "oracle"), "fo_cli"], check=True)
-    tmp = Path(os.environ.get("TMPDIR", "/tmp")) / f"ferbench_{os.getpid()}_{tag}"
-    tmp.mkdir(parents=True, exist_ok=True)
-    src = tmp / "in.yuv"
-    frames_np[:nframes].tofile(src)
     cmd = [str(cli), "enc", str(cfg["W"]), str(cfg["H"]), str(nframes), str(cfg["qp"]), str(cfg["window"]),
-           str(cfg["maxdiff"]), str(cfg["gop"]), "0", str(src), str(tmp / "out.264")]
-    return subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True), tmp
+           str(cfg["maxdiff"]), str(cfg["gop"]), "0", str(tmp / "in.yuv"), str(tmp / "out.264")]
+    return subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
 
 
 def finish_oracle(proc, tmp):
     out = proc.communicate()[0]
+    if proc.returncode != 0:
+        raise SystemExit(f"oracle/fo_cli failed ({proc.returncode})")
     res = json.loads(out.strip().splitlines()[-1])
     for f in tmp.iterdir():
         f.unlink()
@@ -130,7 +139,9 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("FER_BENCH_STREAMS", "256")))
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("FER_BENCH_CONTEXTS", "2")),
                     help="encoder contexts per GPU, each on its own HIP stream and host thread (streams are split evenly)")
-    ap.add_argument("--cpu-frames", type=int, default=3, help="pictures of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=30, help="pictures of the CPU-baseline sample: 30 = one full GOP of one stream, "
+                    "about 70 s on one core, run beside the GPU part (0 = skip)")
+    ap.add_argument("--cpu-nproc-frames", type=int, default=4, help="pictures each process of the N-process CPU leg encodes")
     ap.add_argument("--secondary", type=int, default=1, help="also time configs[1] (720p I-only) and configs[4] (decode)")
     ap.add_argument("--e2e", type=int, default=1, help="also time the PCIe-inclusive path (pinned host pictures in, host RBSP out)")
     ap.add_argument("--probe-build", type=int, default=0, help="development only: a -DFER_PROBE library with FER_DBG set skips "
@@ -138,6 +149,9 @@ def main():
     ap.add_argument("--resolve-wgs", type=int, default=0, help="workgroups of the persistent motion-chain launch (0 = library default)")
     ap.add_argument("--speculate", type=int, default=1, help="0 = the motion chain searches everything itself (no k_me_spec pre-pass)")
     ap.add_argument("--resolve-group", type=int, default=0, help="streams per ticket group of the motion chain (0 = library default)")
+    ap.add_argument("--rehearse-ranks", type=int, default=0, help="1 = rank plumbing only, no GPU and no encoder: spawn the ranks, "
+                    "rendezvous (use --dist-backend gloo), barrier, max-reduce of the step time, and the --config 4k gather + merge "
+                    "of per-GOP streams with placeholder bytes; prints {\"rehearsal\": ...} instead of a bench line")
     ap.add_argument("--dist-backend", default=os.environ.get("FER_BENCH_BACKEND", "nccl"),
                     help="nccl (= RCCL, one rank per GPU) or gloo (rehearsal: several ranks may share GPU 0)")
     args = ap.parse_args()
@@ -153,6 +167,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse_ranks:
+        return rehearse_ranks(args, rank, world, dist, torch, load_pkg())
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -211,6 +227,13 @@ def main():
     parts = [frames[:, bounds[i]:bounds[i + 1]].contiguous() for i in range(NC)]
     del frames
     torch.cuda.synchronize()
+    # the CPU baseline's single-core leg (one full GOP of stream 0 through oracle/fo_cli, about 70 s) starts now and runs
+    # beside the GPU part on one of the host's cores
+    cpu_job = cpu_sample = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0 and args.config == "1080p":
+        cpu_sample = parts[0][:, 0].cpu().numpy()
+        tmp_ = stage_oracle_input(cpu_sample, min(args.cpu_frames, GOP), "one")
+        cpu_job = (run_oracle_enc(cfg, tmp_, min(args.cpu_frames, GOP)), tmp_)
     encs = [pkg.FerHip(W, H, bounds[i + 1] - bounds[i], qp=cfg["qp"], window=cfg["window"], maxdiff=cfg["maxdiff"],
                        intra_every=GOP) for i in range(NC)]
     nmb = encs[0].nmb
@@ -342,8 +365,23 @@ def main():
         check["rbsp_sha256"] = hashlib.sha256(s0).hexdigest()
         check["expected"] = gold.get("bench_1080p_30f_qp12_w32", {}).get("stream_sha256")
         check["bytes"] = len(s0)
+        # more streams: one of every ticket queue of the motion chain (local streams 0..7), the last of the first context,
+        # the first ones of a second context, the last stream -- whichever of them this run has
+        more = gold.get("bench_1080p_30f_qp12_w32_streams", {}).get("stream_sha256", {})
+        bad, seen = [], [0]
+        for key, want in sorted(more.items(), key=lambda kv: int(kv[0])):
+            g_ = int(key)
+            if g_ >= S:
+                continue
+            i = max(k for k in range(NC) if bounds[k] <= g_)
+            got = hashlib.sha256(annexb(i, g_ - bounds[i])).hexdigest()
+            seen.append(g_)
+            if got != want:
+                bad.append(g_)
+        check["streams_checked"] = seen
+        check["streams_bad"] = bad
     if check["expected"] is not None:
-        check["ok"] = check["rbsp_sha256"] == check["expected"]
+        check["ok"] = check["rbsp_sha256"] == check["expected"] and not check.get("streams_bad")
         if not check["ok"] and not args.probe_build:
             raise SystemExit(f"output hash mismatch: {check}")
     del host_rbsp, host_len
@@ -377,15 +415,18 @@ def main():
     # ---- roofline of the dominant kernel (by accumulated device time; every profiled phase is one kernel, except
     # "sort" = the six launches of the two radix passes and "cavlc" = size + scan + emit)
     pics = {"P": (GOP - 1) * args.steps, "I": args.steps, "all": GOP * args.steps}
-    per_mb_traffic = {}
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    per_mb_traffic, limiters = {}, {}
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         tj = ROOT / "profiles" / name
         if tj.exists():
-            per_mb_traffic = json.loads(tj.read_text()).get("bytes_per_mb", {})
+            pj = json.loads(tj.read_text())
+            per_mb_traffic = pj.get("bytes_per_mb", {})
+            limiters = pj.get("limiter", {})
             break
 
     def line(k):
-        name, bpm, limiter, on = KERNELS[k]
+        name, bpm, on = KERNELS[k]
+        limiter = limiters.get(k, "not measured")
         ms_, launches_ = prof.get(k, (0.0, 0))
         units = S * nmb * pics[on]  # accumulated over contexts, like ms_ and launches_
         per_launch_s = (ms_ / 1e3) / max(launches_, 1)
@@ -410,24 +451,25 @@ def main():
     out = None
     if rank == 0:
         cpu = cpu_n = None
-        if world == 1 and args.cpu_frames > 0:
-            sample = parts[0][:, 0].cpu().numpy()
-            p, tmp = run_oracle_enc(cfg, sample, args.cpu_frames, "one")
-            res = finish_oracle(p, tmp)
+        if cpu_job is not None:
+            # the single-core leg ran beside the GPU part (one of the host's cores; fo_cli clocks the encode itself)
+            res = finish_oracle(*cpu_job)
             cpu = {"value": round(res["mb_per_s"], 1), "unit": "macroblocks/s", "cores": 1, "kind": "port",
-                   "sample": f"first {args.cpu_frames} pictures (I+{args.cpu_frames - 1}P) of stream 0, "
-                             f"{res['mbs']} MBs in {res['seconds']:.1f} s, oracle/fo_cli single thread"}
-            # N independent processes over streams (the reference's only route to several cores): N = host cores
+                   "sample": f"first {args.cpu_frames} pictures (I+{args.cpu_frames - 1}P{', one full GOP' if args.cpu_frames == GOP else ''}) "
+                             f"of stream 0, {res['mbs']} MBs in {res['seconds']:.1f} s, oracle/fo_cli single thread, input staged before its clock starts"}
+            # N independent processes (the reference's only route to several cores): N = host cores, a bounded sample each,
+            # inputs staged before the clock starts
             ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            ncpu = max(1, min(ncpu, parts[0].shape[1] if NC == 1 else S, 64))
+            ncpu = max(1, min(ncpu, 64))
+            nf = max(1, min(args.cpu_nproc_frames, GOP))
+            stage = [stage_oracle_input(cpu_sample, nf, f"n{k}") for k in range(ncpu)]
             t2 = time.perf_counter()
-            jobs = [run_oracle_enc(cfg, parts[0][:, k % parts[0].shape[1]].cpu().numpy(), args.cpu_frames, f"n{k}")
-                    for k in range(ncpu)]
-            mbs = sum(finish_oracle(p_, t_)["mbs"] for p_, t_ in jobs)
+            jobs = [run_oracle_enc(cfg, t_, nf) for t_ in stage]
+            mbs = sum(finish_oracle(p_, t_)["mbs"] for p_, t_ in zip(jobs, stage))
             wall = time.perf_counter() - t2
             cpu_n = {"value": round(mbs / wall, 1), "unit": "macroblocks/s", "cores": ncpu, "kind": "port",
-                     "sample": f"{ncpu} fo_cli processes, {args.cpu_frames} pictures of one stream each, wall {wall:.1f} s "
-                               "(input written to disk inside the timed region)"}
+                     "sample": f"{ncpu} fo_cli processes, the first {nf} pictures (I+{nf - 1}P) of stream 0 each, wall {wall:.1f} s, "
+                               "inputs staged before the clock starts"}
         secondary = None
         if world == 1 and args.secondary and args.config == "1080p":
             for e in encs:
@@ -456,6 +498,39 @@ def main():
         print(json.dumps(out), flush=True)
     for e in encs:
         e.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def rehearse_ranks(args, rank, world, dist, torch, pkg):
+    """The multi-rank plumbing of a --gpus N run without a GPU and without an encoder (nothing is encoded: the per-GOP
+    "streams" are placeholder bytes): process-group rendezvous, the barrier + max-over-ranks reduction of the step time,
+    the --config 4k host-side gather of per-GOP streams and their merge in GOP order."""
+    cfg = CONFIGS[args.config]
+    if world > 1:
+        dist.init_process_group("gloo" if args.dist_backend != "nccl" or not torch.cuda.is_available() else "nccl")
+        dist.barrier()
+    dt = 1.0 + rank
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ngops = cfg.get("ngops", world)
+    mine = pkg.gops_of_rank(ngops, world, rank)
+    local_streams = {g: b"\x00\x00\x00\x01" + bytes([0x65, g, rank]) for g in mine}
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local_streams)
+        allg = {}
+        for g_ in gathered:
+            allg.update(g_)
+    else:
+        allg = local_streams
+    if rank == 0:
+        order = [allg[g][5] for g in range(ngops)]
+        owners = [allg[g][6] for g in range(ngops)]
+        print(json.dumps({"rehearsal": True, "world": world, "max_dt": dt, "gops_in_order": order == list(range(ngops)),
+                          "gop_owner": owners}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

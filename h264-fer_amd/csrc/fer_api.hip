@@ -87,6 +87,9 @@ static const int k_qpc[52] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12
                               18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33,
                               34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
 
+// qPiToQPc (F/inttransform.cpp:8-14) for chroma_qp_index_offset 0: what the per-macroblock shims of fer_legacy.hip need
+extern "C" int ferhip_chroma_qp(int qpy) { return k_qpc[qpy < 0 ? 0 : (qpy > 51 ? 51 : qpy)]; }
+
 template <typename T>
 static int dalloc(ferhip_ctx *c, T **p, size_t n)
 {
@@ -205,7 +208,7 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     d.ysz = (size_t)W * H;
     d.csz = d.ysz / 4;
     d.resolve_wgs = 6144;
-    d.resolve_group = 4;
+    d.resolve_group = 16;
     {
         int lo = 0, hi = 0;  // numerically lower = higher priority
         if (hipGetDevice(&c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
@@ -250,6 +253,7 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     rc |= dalloc(c, &d.i4flag, nm * 16);
     rc |= dalloc(c, &d.chroma_mode, nm);
     rc |= dalloc(c, &d.levels, nm * FER_LEVELS);
+    rc |= dalloc(c, &d.mbsize, nm * 2);
     rc |= dalloc(c, &d.suma, decode_only ? (size_t)1 : (size_t)(nm * 20));
     rc |= dalloc(c, &d.st3, decode_only ? (size_t)1 : (size_t)(nm * 4 * 33 * 3));
     rc |= dalloc(c, &d.st3n, decode_only ? (size_t)1 : (size_t)(nm * 4));
@@ -424,13 +428,24 @@ extern "C" int ferhip_upload_frames(ferhip_ctx *c, const void *pinned_src)
     FerDev &d = c->d;
     const size_t bytes = d.ysz * 3 / 2 * d.S;
     if (!c->st_copy) {
-        CK(hipStreamCreateWithFlags(&c->st_copy, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) {
-            CK(dalloc(c, &c->stage[i], bytes) ? hipErrorOutOfMemory : hipSuccess);
-            CK(hipEventCreateWithFlags(&c->up_done[i], hipEventDisableTiming));
-            CK(hipEventCreateWithFlags(&c->up_used[i], hipEventDisableTiming));
+        // first call: the copy stream, two staging sets, their events.  A failure on the way leaves the context as it
+        // was before the call (st_copy null), so that a later call tries again instead of meeting half a setup.
+        hipStream_t stc = nullptr;
+        CK(hipStreamCreateWithFlags(&stc, hipStreamNonBlocking));
+        bool ok = true;
+        for (int i = 0; i < 2 && ok; i++) {
+            if (!c->stage[i]) ok = dalloc(c, &c->stage[i], bytes) == 0;
+            if (ok && !c->up_done[i]) ok = hipEventCreateWithFlags(&c->up_done[i], hipEventDisableTiming) == hipSuccess;
+            if (ok && !c->up_used[i]) ok = hipEventCreateWithFlags(&c->up_used[i], hipEventDisableTiming) == hipSuccess;
         }
-        CK(hipDeviceSynchronize());  // dalloc clears on the null stream
+        if (ok) ok = hipDeviceSynchronize() == hipSuccess;  // dalloc clears on the null stream
+        if (!ok) {
+            (void)hipGetLastError();
+            hipStreamDestroy(stc);
+            fprintf(stderr, "ferhip_upload_frames: could not set up the staging buffers\n");
+            return FERHIP_E_HIP;
+        }
+        c->st_copy = stc;
     }
     if (c->up_ready >= 2) return FERHIP_E_STATE;
     const int k = c->up_next;
@@ -1091,6 +1106,7 @@ extern "C" size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t
     case FERHIP_BUF_ST2N: src = d.st2n; n = nm * 16; break;
     case FERHIP_BUF_ST2: src = d.st2; n = nm * 4 * FER_ST2_CAP * 8; break;
     case FERHIP_BUF_SPEC_STAT: src = d.spec_stat; n = 8 * 8; break;
+    case FERHIP_BUF_MBSIZE: src = d.mbsize; n = nm * 8; break;
     case FERHIP_BUF_CUR:
     case FERHIP_BUF_REF: {
         n = d.ysz * 3 / 2 * d.S;

@@ -195,7 +195,7 @@ __device__ inline void cavlc_block_core(BitW &w, unsigned nz, int maxNumCoeff, i
                 } else {
                     prefix = 15;
                     ss = 12;
-                    suf = (unsigned)(levelCode - 30);
+                    suf = (unsigned)(levelCode - 30) & 0xfffu;  // (levels beyond the escape range, |level| > 2063: see DESIGN.md section 4)
                 }
             } else if (levelCode < (15 << suffixLength)) {
                 prefix = levelCode >> suffixLength;
@@ -204,7 +204,7 @@ __device__ inline void cavlc_block_core(BitW &w, unsigned nz, int maxNumCoeff, i
             } else {
                 prefix = 15;
                 ss = 12;
-                suf = (unsigned)(levelCode - (15 << suffixLength));
+                suf = (unsigned)(levelCode - (15 << suffixLength)) & 0xfffu;
             }
             bw_put<WRITE>(w, prefix, 0);
             bw_put<WRITE>(w, 1, 1);

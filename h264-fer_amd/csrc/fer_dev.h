@@ -90,6 +90,7 @@ struct FerDev {
     uint8_t *i4flag;     // [S][nmb][16] bit3 = prev_intra4x4_pred_mode_flag, bits0-2 = rem
     uint8_t *chroma_mode;  // [S][nmb]
     int16_t *levels;     // [S][nmb][FER_LEVELS]
+    int *mbsize;         // [S][nmb][2] what coded_mb_size returned for the Intra16x16 and the Intra4x4 alternative (I pictures; test read-back)
     // motion-search precompute (neighbour independent)
     int *suma;           // [S][nmb][4][5]
     int *st3;            // [S][nmb][4][33][3] bx, by, sad
@@ -468,6 +469,27 @@ __device__ __forceinline__ int mc_chroma(const uint8_t *__restrict__ R, int Wc, 
     return ((8 - xl) * (8 - yl) * R[y0 + x0] + xl * (8 - yl) * R[y0 + x1] + (8 - xl) * yl * R[y1 + x0] +
             xl * yl * R[y1 + x1] + 32) >>
            6;
+}
+
+// four chroma samples (x .. x+3, y) of the block at (xPc, yPc), F/mocomp.cpp:80-110 (as mc_chroma, sample by sample)
+__device__ __forceinline__ void mc_chroma_row4(const uint8_t *__restrict__ R, int Wc, int Hc, int xPc, int yPc, int x, int y, int mvx,
+                                               int mvy, int out[4])
+{
+    const int by = (y >> 1) << 1, oy = y & 1;
+    const int cy = yPc + by + (mvy >> 3);
+    const uint32_t y0 = __umul24((uint32_t)iclamp(cy + oy, 0, Hc - 1), (uint32_t)Wc), y1 = __umul24((uint32_t)iclamp(cy + oy + 1, 0, Hc - 1), (uint32_t)Wc);
+    const int X = xPc + x + (mvx >> 3);  // x is a multiple of 4: sample k reads columns X + k and X + k + 1
+    int t[5], u[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint32_t xc = (uint32_t)iclamp(X + k, 0, Wc - 1);
+        t[k] = R[y0 + xc];  // (32-bit offsets from the stream's uniform plane base)
+        u[k] = R[y1 + xc];
+    }
+    const int xl = mvx & 7, yl = mvy & 7;
+    const int w00 = (8 - xl) * (8 - yl), w01 = xl * (8 - yl), w10 = (8 - xl) * yl, w11 = xl * yl;
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = (w00 * t[k] + w01 * t[k + 1] + w10 * u[k] + w11 * u[k + 1] + 32) >> 6;
 }
 
 // 4 / 8 consecutive bytes at an arbitrary byte address with aligned dword loads + v_alignbyte

@@ -163,6 +163,8 @@ extern "C" void LoadY4MHeader(void)
     }
     inputWidth = g_in->inW;
     inputHeight = g_in->inH;
+    // planes the library allocated for another picture size are dropped: ReadFromY4M copies W x H samples into them
+    if (frame.L && (frame.Lwidth != g_in->W || frame.Lheight != g_in->H)) ferhip_legacy_frame_drop();
     frame.Lwidth = g_in->W;
     frame.Lheight = g_in->H;
     frame.Cwidth = frame.Lwidth >> 1;

@@ -396,6 +396,10 @@ __global__ __launch_bounds__(64) void k_intra_mb(FerDev d, int diag)
         bits4 = hb + wave_sum((int)w.bits);
     }
     const bool use4 = (unsigned)bits4 < (unsigned)bits16;
+    if (lane == 0) {  // coded_mb_size of either alternative (F/rbsp_encoding.cpp:330): FERHIP_BUF_MBSIZE
+        d.mbsize[mbi * 2] = bits16;
+        d.mbsize[mbi * 2 + 1] = bits4;
+    }
 
     // ---- phase 6: reconstruction and side information of the winner
     int16_t *lv = d.levels + mbi * FER_LEVELS;

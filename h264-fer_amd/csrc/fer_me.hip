@@ -469,8 +469,11 @@ __device__ __forceinline__ int sad_lane(const IPlanes &ip, int W, int H, int sx,
 // ------------------------------------------------------------------ k_me_pre
 #define ME_WIDE_LDS 1156  // (2*16+2)^2: WindowSize <= 32 takes the LDS route (4.6 KB per wave)
 #define ME_SEL_NB 25      // 64-candidate batches of stage 3 at WindowSize 32: 18 wide + 7 local
+#ifndef PRE_WAVES
+#define PRE_WAVES 7  // wavefronts per SIMD the kernel is compiled for (register budget)
+#endif
 template <int WIN>  // WindowSize known at compile time (0 = read it from d): divisions by the window become shifts/muls
-__global__ __launch_bounds__(64, 5) void k_me_pre(FerDev d)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PRE_WAVES, PRE_WAVES))) void k_me_pre(FerDev d)
 {
     const int window = WIN ? WIN : d.window;
     // LDS of the wavefront: region A = the row sums of the local search, then the wide search's metrics; region B =
@@ -1607,8 +1610,11 @@ __device__ __forceinline__ ResNbr nbr_from_field(const FerDev &d, const int *vf,
 // guess against the true predictor and prices the lists (SAD + |mv - mvp|); a wrong guess sends it through its own search.
 // Partition 0 also tries the P_Skip test for the guessed P_Skip vector; when it passes, the other three wavefronts skip
 // their searches (the macroblock will most likely be skipped).
+#ifndef SPEC_WAVES
+#define SPEC_WAVES 7
+#endif
 template <int WIN>
-__global__ __launch_bounds__(256) void k_me_spec(FerDev d)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC_WAVES, SPEC_WAVES))) void k_me_spec(FerDev d)
 {
     __shared__ __attribute__((aligned(16))) uint32_t loc_all[4][LocalGeo<2>::HTAB + LocalGeo<2>::NB * 64];  // row sums (later the selection's scratch), metrics
     __shared__ int skipflag;
@@ -1702,7 +1708,7 @@ __device__ __forceinline__ void res_spec_load(const FerDev &d, bool spec, size_t
 // thousands of rows in flight the launch is bound by how many instructions it issues, not by the latency of a row: a
 // second wavefront per row (which the chain's own search used to be split over) would only repeat them.
 template <int WIN>
-__global__ __launch_bounds__(64, RES_WAVES) void k_me_resolve(FerDev d)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RES_WAVES, RES_WAVES))) void k_me_resolve(FerDev d)
 {
     __shared__ __attribute__((aligned(16))) uint32_t loc_lds[LocalGeo<2>::HTAB + LocalGeo<2>::NB * 64];  // the chain's own search: row sums / selection scratch, metrics
     const int lane = threadIdx.x;
@@ -1961,7 +1967,9 @@ __global__ __launch_bounds__(64) void k_basic_stat(FerDev d)
         for (int k = 0; k < 4; k++) src[y][k] = (v >> (8 * k)) & 0xff;
     }
     const int R = d.window / 2, n = 2 * R + 1;
-    int best = 0x7fffffff;  // sad << 13 | arrival index (n * n <= 4225 at WindowSize 64)
+    // the first minimum in arrival order: per lane (its candidates arrive in increasing order: strict <), then over the lanes
+    // by SAD, then by arrival index among the lanes that hold that SAD (no packing of the two: any WindowSize)
+    int bsad = 0x7fffffff, bidx = 0x7fffffff;
     for (int c = lane; c < n * n; c += 64) {
         const int mvx = c / n - R, mvy = c % n - R;  // quarter-pel units, tmvx outer, tmvy inner
         int sad = 0;
@@ -1972,10 +1980,14 @@ __global__ __launch_bounds__(64) void k_basic_stat(FerDev d)
 #pragma unroll
             for (int k = 0; k < 4; k++) sad += iabs(src[y][k] - p[k]);
         }
-        best = min(best, (sad << 13) | c);
+        if (sad < bsad) {
+            bsad = sad;
+            bidx = c;
+        }
     }
-    const int w = wave_min(best);
-    if (lane == 0) atomicAdd(&d.stats[s * 5 + ((w & 0x1fff) == 0 ? 1 : 4)], 1);
+    const int wsad = wave_min(bsad);
+    const int widx = wave_min(bsad == wsad ? bidx : 0x7fffffff);
+    if (lane == 0) atomicAdd(&d.stats[s * 5 + (widx == 0 ? 1 : 4)], 1);
 }
 
 void fer_launch_basic_stat(const FerDev &d, hipStream_t st)

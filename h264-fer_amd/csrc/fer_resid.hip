@@ -16,27 +16,6 @@
 #include "fer_internal.h"
 #include "fer_mvpred.h"
 
-// four chroma samples (x .. x+3, y) of the block at (xPc, yPc), F/mocomp.cpp:80-110 (as mc_chroma, sample by sample)
-__device__ __forceinline__ void mc_chroma_row4(const uint8_t *__restrict__ R, int Wc, int Hc, int xPc, int yPc, int x, int y, int mvx,
-                                               int mvy, int out[4])
-{
-    const int by = (y >> 1) << 1, oy = y & 1;
-    const int cy = yPc + by + (mvy >> 3);
-    const uint32_t y0 = __umul24((uint32_t)iclamp(cy + oy, 0, Hc - 1), (uint32_t)Wc), y1 = __umul24((uint32_t)iclamp(cy + oy + 1, 0, Hc - 1), (uint32_t)Wc);
-    const int X = xPc + x + (mvx >> 3);  // x is a multiple of 4: sample k reads columns X + k and X + k + 1
-    int t[5], u[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const uint32_t xc = (uint32_t)iclamp(X + k, 0, Wc - 1);
-        t[k] = R[y0 + xc];  // (32-bit offsets from the stream's uniform plane base)
-        u[k] = R[y1 + xc];
-    }
-    const int xl = mvx & 7, yl = mvy & 7;
-    const int w00 = (8 - xl) * (8 - yl), w01 = xl * (8 - yl), w10 = (8 - xl) * yl, w11 = xl * yl;
-#pragma unroll
-    for (int k = 0; k < 4; k++) out[k] = (w00 * t[k] + w01 * t[k + 1] + w10 * u[k] + w11 * u[k + 1] + 32) >> 6;
-}
-
 // A workgroup = four wavefronts = four macroblocks side by side (64-byte picture segments), and the workgroups are
 // dealt so that each XCD works on one contiguous band of the picture: a picture line is then fetched into ONE L2, once,
 // instead of by every XCD that happens to own one of its 16-sample pieces.  The wavefronts share nothing: their LDS

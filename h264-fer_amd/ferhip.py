@@ -8,11 +8,11 @@ import numpy as np
 NAL_SLICE, NAL_IDR, NAL_AUTO = 1, 5, 0
 
 BUF = dict(INTERP=1, FEAT=2, SORTPOS=3, KOLIKO=4, MBTYPE=5, MV=6, MVD=7, LEVELS=8, CBP=9, TC=10, I4MODE=11,
-           CUR=12, REF=13, TIMING=14, ST2N=15, ST2=16, SPEC_STAT=17)
+           CUR=12, REF=13, TIMING=14, ST2N=15, ST2=16, SPEC_STAT=17, MBSIZE=18)
 TUNE_RESOLVE_WGS, TUNE_RESOLVE_GROUP, TUNE_SPECULATE = 1, 2, 3
 _BUF_DTYPE = {1: np.uint8, 2: np.uint16, 3: np.uint32, 4: np.int32, 5: np.int32, 6: np.int16, 7: np.int16,
               8: np.int16, 9: np.uint8, 10: np.uint8, 11: np.uint8, 12: np.uint8, 13: np.uint8, 14: np.int64, 15: np.int32, 16: np.int32,
-              17: np.uint64}
+              17: np.uint64, 18: np.int32}
 
 
 class FerHipError(RuntimeError):
@@ -257,7 +257,7 @@ class FerHip:
         n = self.nmb * self.S
         px = self.W * self.H * self.S
         count = {1: px * 16, 2: px * 96, 3: px, 4: 16385 * self.S, 5: n, 6: n * 8, 7: n * 8, 8: n * 400, 9: n * 2,
-                 10: n * 24, 11: n * 16, 12: self.fsz * self.S, 13: self.fsz * self.S, 14: 64, 15: n * 4, 16: n * 4 * 384 * 2, 17: 8}[which]
+                 10: n * 24, 11: n * 16, 12: self.fsz * self.S, 13: self.fsz * self.S, 14: 64, 15: n * 4, 16: n * 4 * 384 * 2, 17: 8, 18: n * 2}[which]
         out = np.empty(count, _BUF_DTYPE[which])
         got = self.lib.ferhip_read_buffer(self.ctx, which, out.ctypes.data, out.nbytes)
         if got != out.nbytes:
@@ -309,6 +309,67 @@ def inverse_residual(qp, blocks, keep_dc=False):
     _chk(lib.ferhip_inverse_residual(qp, a.ctypes.data, out.ctypes.data, int(keep_dc), a.shape[0]),
          "ferhip_inverse_residual")
     return out
+
+
+class MbJob(C.Structure):
+    """ferhip_mb_job of include/ferhip.h"""
+    _fields_ = [("op", C.c_int32), ("cls", C.c_int32), ("qp", C.c_int32), ("qpc", C.c_int32), ("reconstruct", C.c_int32), ("blk", C.c_int32),
+                ("srcY", C.c_int32 * 256), ("srcCb", C.c_int32 * 64), ("srcCr", C.c_int32 * 64),
+                ("predY", C.c_int32 * 256), ("predCb", C.c_int32 * 64), ("predCr", C.c_int32 * 64),
+                ("lumaLevel", C.c_int32 * 256), ("dc16", C.c_int32 * 16), ("ac16", C.c_int32 * 256), ("cdc", C.c_int32 * 8), ("cac", C.c_int32 * 128)]
+
+
+class MbResult(C.Structure):
+    _fields_ = [("lumaLevel", C.c_int32 * 256), ("dc16", C.c_int32 * 16), ("ac16", C.c_int32 * 256), ("cdc", C.c_int32 * 8), ("cac", C.c_int32 * 128),
+                ("recY", C.c_int32 * 256), ("recCb", C.c_int32 * 64), ("recCr", C.c_int32 * 64)]
+
+
+MBU_QT, MBU_DEC4, MBU_DEC16, MBU_DECC, MBU_SKIP = range(5)
+
+
+def mb_unit(jobs):
+    """ferhip_mb_unit: jobs = list of dicts (fields of ferhip_mb_job, arrays as numpy) -> list of dicts of numpy arrays"""
+    lib = load_library()
+    n = len(jobs)
+    J = (MbJob * n)()
+    R = (MbResult * n)()
+    for k, j in enumerate(jobs):
+        for name, val in j.items():
+            if isinstance(val, (int, np.integer)):
+                setattr(J[k], name, int(val))
+            else:
+                a = np.ascontiguousarray(val, np.int32).reshape(-1)
+                C.memmove(getattr(J[k], name), a.ctypes.data, a.nbytes)
+    lib.ferhip_mb_unit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    _chk(lib.ferhip_mb_unit(J, R, n), "ferhip_mb_unit")
+    return [{f: np.frombuffer(getattr(R[k], f), np.int32).copy() for f, _ in MbResult._fields_} for k in range(n)]
+
+
+def cavlc_blocks(coef, nC, max_num_coeff):
+    """ferhip_cavlc_blocks -> (bits [n][64] uint8, nbits [n], total_coeff [n])"""
+    lib = load_library()
+    c = np.ascontiguousarray(coef, np.int32).reshape(-1, 16)
+    n = c.shape[0]
+    nc = np.ascontiguousarray(nC, np.int32)
+    mx = np.ascontiguousarray(max_num_coeff, np.int32)
+    bits = np.zeros((n, 64), np.uint8)
+    nb = np.zeros(n, np.uint32)
+    tc = np.zeros(n, np.int32)
+    lib.ferhip_cavlc_blocks.argtypes = [C.c_void_p] * 3 + [C.c_size_t] + [C.c_void_p] * 3
+    _chk(lib.ferhip_cavlc_blocks(c.ctypes.data, nc.ctypes.data, mx.ctypes.data, n, bits.ctypes.data, nb.ctypes.data, tc.ctypes.data), "ferhip_cavlc_blocks")
+    return bits, nb, tc
+
+
+def mc_sub_mb_parts(ref_i420, width, height, desc):
+    """ferhip_mc_sub_mb_parts: desc [n][5] = mb, subMbIdx, subMbPartIdx, mvx, mvy -> (predL [n][4][4], predCb [n][2][2], predCr [n][2][2])"""
+    lib = load_library()
+    r = np.ascontiguousarray(ref_i420, np.uint8)
+    d = np.ascontiguousarray(desc, np.int32).reshape(-1, 5)
+    n = d.shape[0]
+    pl, pb, pr = np.zeros((n, 4, 4), np.int32), np.zeros((n, 2, 2), np.int32), np.zeros((n, 2, 2), np.int32)
+    lib.ferhip_mc_sub_mb_parts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    _chk(lib.ferhip_mc_sub_mb_parts(r.ctypes.data, width, height, d.ctypes.data, n, pl.ctypes.data, pb.ctypes.data, pr.ctypes.data), "ferhip_mc_sub_mb_parts")
+    return pl, pb, pr
 
 
 def block_op(name, blocks, qp=0, flag=None):

@@ -171,6 +171,8 @@ int ferhip_inter_encoding(ferhip_ctx *c);
 #define FERHIP_BUF_ST2N 15    /* int32  [S][nmb][4] stage-2 candidates of every 8x8 partition (before the list cap) */
 #define FERHIP_BUF_SPEC_STAT 17 /* uint64 [8] since the context was created: partitions the motion chain decided, of which the guessed
                                  predictor was right, P_Skip verdicts needed, of which taken from the guess */
+#define FERHIP_BUF_MBSIZE 18   /* int32  [S][nmb][2] coded_mb_size (F/rbsp_encoding.cpp:330) of the Intra16x16 and of the Intra4x4 alternative of every
+                                 macroblock of the last I picture */
 #define FERHIP_BUF_ST2 16     /* int32  [S][nmb][4][384][2] the candidates (position relative to the block, feature distance); a crowded
                                  partition (count > 384) holds its summary instead: [40] = (last step, distance bound), [41] = (zeros, 0) */
 size_t ferhip_read_buffer(ferhip_ctx *c, int which, void *dst, size_t cap);
@@ -231,6 +233,39 @@ int ferhip_inverse_dc_chroma(int qP, const int32_t *in, int32_t *out, size_t nbl
  * = scanChroma) and transformInverseScan(list, c) (F/scaleTransform.cpp:454) */
 int ferhip_transform_scan(const int32_t *in, int32_t *out, int intra16x16_ac, size_t nblocks);
 int ferhip_transform_inverse_scan(const int32_t *in, int32_t *out, size_t nblocks);
+
+/* ---- per-macroblock unit-parity surface (SURVEY.md 8b "per-MB"): the reference's macroblock-level functions as batched
+ * device calls over the same device functions the encode / decode kernels are built from.  A seam for known-answer tests,
+ * not a fast path.  Arrays use the reference's own layouts: samples raster [y][x], levels per luma4x4BlkIdx in scan order
+ * (the Intra16x16 AC / chroma AC lists hold 15 entries from index 0). */
+#define FERHIP_MBU_QT 0    /* quantizationTransform(predL, predCb, predCr, reconstruct), F/quantizationTransform.cpp:349 */
+#define FERHIP_MBU_DEC4 1  /* transformDecoding4x4LumaResidual(LumaLevel, predL, luma4x4BlkIdx, QPy), F/inttransform.cpp:133 */
+#define FERHIP_MBU_DEC16 2 /* transformDecodingIntra_16x16Luma(DC, AC, predL, QPy), F/inttransform.cpp:157 */
+#define FERHIP_MBU_DECC 3  /* transformDecodingChroma(DC, AC, predC, QPy, Cb) for both planes, F/inttransform.cpp:237 */
+#define FERHIP_MBU_SKIP 4  /* transformDecodingP_Skip(predL, predCb, predCr, QPy), F/inttransform.cpp:215 */
+typedef struct {
+    int32_t op, cls /* MbPartPredMode(mb_type,0): 0 Intra_4x4, 1 Intra_16x16, 2 inter */, qp /* QPy */, qpc /* QPc */, reconstruct, blk;
+    int32_t srcY[256], srcCb[64], srcCr[64];    /* the macroblock of `frame` (FERHIP_MBU_QT) */
+    int32_t predY[256], predCb[64], predCr[64];
+    int32_t lumaLevel[16][16], dc16[16], ac16[16][16], cdc[2][4], cac[2][4][16]; /* levels in (decode-side ops) */
+} ferhip_mb_job;
+typedef struct {
+    int32_t lumaLevel[16][16], dc16[16], ac16[16][16], cdc[2][4], cac[2][4][16]; /* levels out (FERHIP_MBU_QT) */
+    int32_t recY[256], recCb[64], recCr[64];    /* samples written into `frame` (0 where the call writes none) */
+} ferhip_mb_result;
+int ferhip_mb_unit(const ferhip_mb_job *jobs, ferhip_mb_result *results, size_t njobs);
+/* residual_block_cavlc_write(coeffLevel, 0, maxNumCoeff - 1, maxNumCoeff) (F/residual.cpp:374) for n blocks with nC given
+ * (-1 = chroma DC): bits[n][64] receives each block's code MSB first, nbits[n] its length -- also what
+ * residual_block_cavlc_size (F/residual.cpp:673) returns; the call fails if the device's counting form disagrees --,
+ * total_coeff[n] the TotalCoeff the block leaves for its neighbours */
+int ferhip_cavlc_blocks(const int32_t *coef, const int32_t *nC, const int32_t *max_num_coeff, size_t nblocks, uint8_t *bits,
+                        uint32_t *nbits, int32_t *total_coeff);
+/* MotionCompensateSubMBPart(predL, predCr, predCb, refPic, mbPartIdx, subMbIdx, subMbPartIdx) (F/mocomp.cpp:152) for n
+ * sub-blocks of one reference picture (host I420, width x height): desc[n][5] = macroblock address, subMbIdx, subMbPartIdx,
+ * mvx, mvy (quarter samples); predL[n][16] = the 4x4 luma block, predCb / predCr[n][4] = the 2x2 chroma blocks (raster).
+ * Chroma is also evaluated through the four-samples-per-row form the residual kernel uses; the call fails if they differ. */
+int ferhip_mc_sub_mb_parts(const uint8_t *ref_i420, int width, int height, const int32_t *desc, size_t n, int32_t *predL,
+                           int32_t *predCb, int32_t *predCr);
 
 #ifdef __cplusplus
 }

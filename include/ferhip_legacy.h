@@ -81,6 +81,38 @@ void inverseResidual(int bitDepth, int qP, int c[4][4], int r[4][4], unsigned ch
 void InverseDCLumaIntra(int bitDepth, int qP, int c[4][4], int dcY[4][4]);
 void InverseDCChroma(int bitDepth, int qP, int c[2][2], int dcC[2][2]);
 
+/* ---- per-macroblock entry points (the "per-MB" row of SURVEY.md 8b): one macroblock per call, through the same device
+ * functions the kernels use (ferhip_mb_unit, ferhip_cavlc_blocks, ferhip_mc_sub_mb_parts of ferhip.h).  They work on the
+ * reference's own globals: the macroblock CurrMbAddr of `frame` (F/h264_globals.h:181), QPy (:179), mb_type (:106), the
+ * level arrays of F/residual.h, the vector arrays of F/mode_pred.h. */
+extern int CurrMbAddr, QPy, mb_type;
+extern int LumaLevel[16][16], Intra16x16DCLevel[16], Intra16x16ACLevel[16][16];
+extern int ChromaDCLevel[2][4], ChromaACLevel[2][4][16];
+extern int ***mvL0x, ***mvL0y; /* [macroblock][subMbIdx][subMbPartIdx], quarter samples (F/mode_pred.h) */
+extern frame_type dpb;         /* the reference picture Decode() predicts from (RefPicList0[0].frame, F/ref_frames.cpp) */
+void AllocateMemory(void);     /* F/mode_pred.cpp:22: sizes mvL0x / mvL0y from `frame` */
+/* what the reference keeps where a caller of the bare functions cannot reach it:
+ * ferhip_legacy_slice_type = shd.slice_type (MbPartPredMode reads it, F/h264_globals.h:123; RBSP_encode sets it);
+ * ferhip_legacy_nC = the nC residual_block_cavlc_write / _size use (the reference derives it from file-statics that only
+ * its residual_write() sets, F/residual.cpp:433-538; -1 = chroma DC); ferhip_legacy_bits / _nbits = where
+ * residual_block_cavlc_write appends (the bit writer F/rbsp_IO.cpp is a leaf file the maintainer keeps) */
+extern int ferhip_legacy_slice_type, ferhip_legacy_nC;
+extern unsigned char ferhip_legacy_bits[1 << 16];
+extern unsigned int ferhip_legacy_nbits;
+void quantizationTransform(int predL[16][16], int predCb[8][8], int predCr[8][8], unsigned char reconstruct);              /* F/quantizationTransform.cpp:349 */
+void transformDecoding4x4LumaResidual(int LumaLevel[16][16], int predL[16][16], int luma4x4BlkIdx, int QPy);               /* F/inttransform.cpp:133 */
+void transformDecodingIntra_16x16Luma(int Intra16x16DCLevel[16], int Intra16x16ACLevel[16][16], int predL[16][16], int QPy); /* :157 */
+void transformDecodingP_Skip(int predL[16][16], int predCb[8][8], int predCr[8][8], int QPy);                              /* :215 */
+void transformDecodingChroma(int ChromaDCLevel[4], int ChromaACLevel[4][16], int predC[8][8], int QPy, unsigned char Cb);  /* :237 */
+void residual_block_cavlc_write(int coeffLevel[16], int startIdx, int endIdx, int maxNumCoeff);                            /* F/residual.cpp:374 */
+unsigned int residual_block_cavlc_size(int coeffLevel[16], int startIdx, int endIdx, int maxNumCoeff);                     /* :673 */
+void MotionCompensateSubMBPart(int predL[16][16], int predCr[8][8], int predCb[8][8], frame_type *refPic, int mbPartIdx, int subMbIdx,
+                               int subMbPartIdx);                                                                         /* F/mocomp.cpp:152 */
+void Decode(int predL[16][16], int predCr[8][8], int predCb[8][8]);                                                        /* :200 */
+/* coded_mb_size (F/rbsp_encoding.cpp:330) and intraPrediction / intraPredictionEncoding (F/intra.cpp:770,949) have no
+ * stand-alone shim: their device form is the body of k_intra_mb, which needs the reconstructed neighbourhood of a whole
+ * picture.  Their unit parity is checked on every macroblock of a picture through ferhip_read_buffer(FERHIP_BUF_MBSIZE). */
+
 #ifdef __cplusplus
 }
 #endif

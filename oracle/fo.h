@@ -161,6 +161,8 @@ typedef struct fo_ctx {
     int (*ref_idx_l0)[4];
     /* test hook: MV field of the last picture saved before FillInterpolatedRefFrame clobbers it */
     int (*dbg_mvx)[4][4], (*dbg_mvy)[4][4];
+    /* test hook: what coded_mb_size returned for the Intra16x16 / Intra4x4 alternative of every macroblock (I pictures) */
+    int (*dbg_mbsize)[2];
 } fo_ctx;
 
 fo_ctx *fo_create(int W, int H);

@@ -41,3 +41,22 @@ void fo_dbg_set_frame(fo_ctx *c, const uint8_t *y, const uint8_t *u, const uint8
     memcpy(c->C[0], u, (size_t)c->Wc * c->Hc);
     memcpy(c->C[1], v, (size_t)c->Wc * c->Hc);
 }
+
+/* coded_mb_size of the Intra16x16 / Intra4x4 alternative of every macroblock of the last I picture */
+int *fo_dbg_mbsize(fo_ctx *c) { return &c->dbg_mbsize[0][0]; }
+/* context-free pieces for the per-macroblock KATs: one macroblock of a W x H context */
+void fo_dbg_set_mb(fo_ctx *c, int cur, int mb_type, int slice_type, int qp)
+{
+    c->cur = cur;
+    c->cur_mb_type = mb_type;
+    c->mb_type[cur] = mb_type;
+    c->slice_type = slice_type;
+    c->QPy = qp;
+}
+int *fo_dbg_levels(fo_ctx *c) { return &c->lv.Lumalevel[0][0]; } /* fo_levels: Lumalevel[16][16], DC16[16], AC16[16][16], CDC[2][4], CAC[2][4][16] */
+void fo_dbg_set_mv(fo_ctx *c, int mb, int sub, int part, int mvx, int mvy)
+{
+    c->mvx[mb][sub][part] = mvx;
+    c->mvy[mb][sub][part] = mvy;
+}
+uint8_t *fo_dbg_dpb(fo_ctx *c, int k) { return k == 0 ? c->dL : c->dC[k - 1]; }

@@ -39,6 +39,7 @@ fo_ctx *fo_create(int W, int H)
     c->refidx = (int *)calloc((size_t)c->nmb, sizeof(int));
     c->ref_idx_l0 = calloc((size_t)c->nmb, sizeof *c->ref_idx_l0);
     c->dbg_mvx = calloc((size_t)c->nmb, sizeof *c->dbg_mvx);
+    c->dbg_mbsize = calloc((size_t)c->nmb, sizeof *c->dbg_mbsize);
     c->dbg_mvy = calloc((size_t)c->nmb, sizeof *c->dbg_mvy);
     /* defaults of F/h264_globals.cpp:217,301-306 and the GUI */
     c->qp = 12;
@@ -71,6 +72,7 @@ void fo_destroy(fo_ctx *c)
     free(c->refidx);
     free(c->ref_idx_l0);
     free(c->dbg_mvx);
+    free(c->dbg_mbsize);
     free(c->dbg_mvy);
     for (int i = 0; i < 16; i++) {
         free(c->interp[i]);

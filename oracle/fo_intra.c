@@ -488,6 +488,10 @@ int fo_intraPredictionEncoding(fo_ctx *c, int predL[16][16], int predCr[8][8], i
         fo_transformDecoding4x4Luma(c, c->lv.Lumalevel, predL, blk, c->QPy);
     }
     unsigned bits4 = fo_coded_mb_size(c, -1, predL, predCb, predCr);
+    if (c->dbg_mbsize) {
+        c->dbg_mbsize[c->cur][0] = (int)min;
+        c->dbg_mbsize[c->cur][1] = (int)bits4;
+    }
     if (bits4 < min) return -1;
     for (int i = 0; i < 16; i++)
         for (int j = 0; j < 16; j++) c->L[(yP + i) * c->W + xP + j] = orig[i][j];

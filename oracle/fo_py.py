@@ -53,6 +53,19 @@ def lib():
         L.fo_invscan.argtypes = [vp, vp]
         L.fo_cavlc_encode_block.restype = C.c_uint
         L.fo_cavlc_encode_block.argtypes = [vp, vp, i, i, vp]
+        L.fo_bw_init.argtypes = [vp, vp, sz]
+        L.fo_dbg_mbsize.restype = vp
+        L.fo_dbg_mbsize.argtypes = [vp]
+        L.fo_dbg_levels.restype = vp
+        L.fo_dbg_levels.argtypes = [vp]
+        L.fo_dbg_set_mb.argtypes = [vp, i, i, i, i]
+        L.fo_dbg_set_mv.argtypes = [vp, i, i, i, i, i]
+        L.fo_mc_sub.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i]
+        L.fo_quantizationTransform.argtypes = [vp, vp, vp, vp, i]
+        L.fo_transformDecoding4x4Luma.argtypes = [vp, vp, vp, i, i]
+        L.fo_transformDecoding16x16Luma.argtypes = [vp, vp, vp, vp, i]
+        L.fo_transformDecodingChroma.argtypes = [vp, vp, vp, vp, i, i]
+        L.fo_transformDecodingPSkip.argtypes = [vp, vp, vp, vp, i]
         _lib = L
     return _lib
 
@@ -134,8 +147,62 @@ class Oracle:
         """brojTipova[5]: P_Skip, 16x16, 16x8, 8x16, 8x8 macroblocks so far"""
         return _arr(self.L.fo_dbg_type_count(self.c), 5, np.int32).copy()
 
+    def mbsize(self):
+        """coded_mb_size of the Intra16x16 / Intra4x4 alternative of every macroblock of the last I picture"""
+        return _arr(self.L.fo_dbg_mbsize(self.c), self.nmb * 2, np.int32).reshape(self.nmb, 2).copy()
+
+    # ---- one macroblock at a time (per-macroblock KATs)
+    LEVELS = (("lumaLevel", 256), ("dc16", 16), ("ac16", 256), ("cdc", 8), ("cac", 128))
+
+    def set_mb(self, cur, mb_type, slice_type, qp):
+        self.L.fo_dbg_set_mb(self.c, cur, mb_type, slice_type, qp)
+
+    def levels(self):
+        a = _arr(self.L.fo_dbg_levels(self.c), 664, np.int32)
+        out, o = {}, 0
+        for n, k in self.LEVELS:
+            out[n] = a[o:o + k].copy()
+            o += k
+        return out
+
+    def set_levels(self, **kw):
+        a = _arr(self.L.fo_dbg_levels(self.c), 664, np.int32)
+        o = 0
+        for n, k in self.LEVELS:
+            if n in kw:
+                a[o:o + k] = np.asarray(kw[n], np.int32).reshape(-1)
+            o += k
+
+    def quantization_transform(self, predL, predCb, predCr, reconstruct):
+        p = [np.ascontiguousarray(x, np.int32) for x in (predL, predCb, predCr)]
+        self.L.fo_quantizationTransform(self.c, p[0].ctypes.data, p[1].ctypes.data, p[2].ctypes.data, int(reconstruct))
+
+    def mc_sub(self, mb, sub, part, mvx, mvy):
+        """MotionCompensateSubMBPart against the context's dpb -> (4x4 luma, 2x2 Cb, 2x2 Cr)"""
+        self.L.fo_dbg_set_mv(self.c, mb, sub, part, mvx, mvy)
+        pl, pr, pb = np.zeros((16, 16), np.int32), np.zeros((8, 8), np.int32), np.zeros((8, 8), np.int32)
+        self.L.fo_mc_sub(self.c, pl.ctypes.data, pr.ctypes.data, pb.ctypes.data, self.L.fo_dbg_plane(self.c, 3), self.L.fo_dbg_plane(self.c, 4),
+                         self.L.fo_dbg_plane(self.c, 5), mb, sub, part)
+        oy, ox = ((sub & 2) << 2) + ((part & 2) << 1), ((sub & 1) << 3) + ((part & 1) << 2)
+        return pl[oy:oy + 4, ox:ox + 4].copy(), pb[oy // 2:oy // 2 + 2, ox // 2:ox // 2 + 2].copy(), pr[oy // 2:oy // 2 + 2, ox // 2:ox // 2 + 2].copy()
+
     def cbp(self):
         return np.stack([_arr(self.L.fo_dbg_cbp(self.c, k), self.nmb, np.int32) for k in range(2)], -1).copy()
+
+
+class _BW(C.Structure):
+    _fields_ = [("buf", C.c_void_p), ("cap", C.c_size_t), ("nbits", C.c_size_t)]
+
+
+def cavlc_encode_block(coef, max_num_coeff, nC):
+    """residual_block_cavlc_write of one block with nC given -> (bytes MSB first, bits, TotalCoeff)"""
+    L = lib()
+    buf = np.zeros(128, np.uint8)
+    w = _BW(buf.ctypes.data, buf.size, 0)
+    c = np.ascontiguousarray(coef, np.int32)
+    tc = C.c_int(0)
+    n = L.fo_cavlc_encode_block(C.byref(w), c.ctypes.data, int(max_num_coeff), int(nC), C.byref(tc))
+    return buf[:(n + 7) // 8].tobytes(), int(n), tc.value
 
 
 def forward_residual(qp, blocks, keep_dc=False):

@@ -288,7 +288,8 @@ def test_bad_arguments_are_rejected(pkg):
         pkg.FerHip(176, 144, 0)          # no streams
 
 
-@pytest.mark.parametrize("W,H,T,qp,window,noise", [(176, 144, 5, 12, 16, 2), (176, 144, 4, 12, 32, 0), (1920, 1072, 2, 12, 32, 2)])
+@pytest.mark.parametrize("W,H,T,qp,window,noise", [(176, 144, 5, 12, 16, 2), (176, 144, 4, 12, 32, 0), (1920, 1072, 2, 12, 32, 2),
+                                                    (64, 48, 2, 12, 96, 2)])  # WindowSize 96: 9409 candidates per partition, beyond a 13-bit index
 def test_basic_inter_encoding_matches_oracle(pkg, fo, W, H, T, qp, window, noise):
     """BasicInterEncoding = 1 (F/moestimation.cpp:394-397,470): the exhaustive pass whose vectors the reference
     discards leaves only brojTipova behind; stages 2 and 3 of the feature search are skipped.  Bitstream,

@@ -130,6 +130,20 @@ def test_two_rank_gloo_gop_sharding(tmp_path):
     assert "OK" in outs[0]
 
 
+def test_bench_rank_plumbing_at_world_8():
+    """`bench.py --gpus 8` cold: the parent spawns eight ranks before anything touches a GPU, they rendezvous on 127.0.0.1,
+    reduce the step time with MAX and gather + merge the eight 4K GOP streams in GOP order (rehearsal mode: gloo, no GPU, no
+    encoder -- placeholder bytes stand for the streams)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FER_BENCH_CHILD")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--config", "4k", "--rehearse-ranks", "1", "--dist-backend", "gloo"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["rehearsal"] and line["world"] == 8 and line["max_dt"] == 8.0 and line["gops_in_order"]
+    assert line["gop_owner"] == [g % 8 for g in range(8)]   # GOP g belongs to rank g % world (gops_of_rank)
+
+
 def _write_y4m(path, W, H, frames, params=False):
     with open(path, "wb") as f:
         f.write(b"YUV4MPEG2 W%d H%d F25:1 Ip A1:1 C420jpeg\n" % (W, H))

@@ -5,7 +5,7 @@ set -e
 name=$1; flags=$2
 cd "$(dirname "$0")/../h264-fer_amd/csrc"
 rm -rf /tmp/fervar_$name && mkdir -p /tmp/fervar_$name ../var
-for f in fer_api fer_refprep fer_me fer_resid fer_intra fer_cavlc fer_legacy fer_decode fer_fileio; do
+for f in fer_api fer_refprep fer_me fer_resid fer_intra fer_cavlc fer_legacy fer_decode fer_fileio fer_mbunit; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -Wno-unused-value -I../../include $flags -c $f.hip -o /tmp/fervar_$name/$f.o 2>/dev/null &
 done
 wait
