@@ -137,7 +137,7 @@ def main():
                     help="synthetic content variant: letterbox = 128 black-ish rows top and bottom, flat-half = left half one "
                          "value (large flat areas), still = no motion and no noise (P_Skip heavy)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("FER_BENCH_STREAMS", "256")))
-    ap.add_argument("--contexts", type=int, default=int(os.environ.get("FER_BENCH_CONTEXTS", "2")),
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("FER_BENCH_CONTEXTS", "1")),
                     help="encoder contexts per GPU, each on its own HIP stream and host thread (streams are split evenly)")
     ap.add_argument("--cpu-frames", type=int, default=30, help="pictures of the CPU-baseline sample: 30 = one full GOP of one stream, "
                     "about 70 s on one core, run beside the GPU part (0 = skip)")
@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--probe-build", type=int, default=0, help="development only: a -DFER_PROBE library with FER_DBG set skips "
                     "stages on purpose, so a wrong output hash is reported (\"ok\": false) instead of ending the run")
     ap.add_argument("--resolve-wgs", type=int, default=0, help="workgroups of the persistent motion-chain launch (0 = library default)")
+    ap.add_argument("--overlap-sort", type=int, default=0, help="0 = the sort of the reference picture runs before k_me_pre instead of beside it")
     ap.add_argument("--speculate", type=int, default=1, help="0 = the motion chain searches everything itself (no k_me_spec pre-pass)")
     ap.add_argument("--resolve-group", type=int, default=0, help="streams per ticket group of the motion chain (0 = library default)")
     ap.add_argument("--rehearse-ranks", type=int, default=0, help="1 = rank plumbing only, no GPU and no encoder: spawn the ranks, "
@@ -245,6 +246,7 @@ def main():
         if args.resolve_group:
             e.tune(2, args.resolve_group)
         e.tune(3, args.speculate)
+        e.tune(4, args.overlap_sort)
 
     def run_ctx(i, sink=None):
         e, fr = encs[i], parts[i]

@@ -34,7 +34,9 @@ struct ferhip_ctx {
     ferhip_params p;
     hipStream_t st;
     hipStream_t st_hi;   // high-priority stream for the latency-bound per-diagonal chains
-    hipEvent_t ev_a, ev_b;
+    hipStream_t st_aux;  // the sort of the reference picture's positions runs here, beside k_me_pre (run_picture)
+    hipEvent_t ev_a, ev_b, ev_c, ev_d;
+    int overlap_sort;    // ferhip_tune: 1 / 2 = the HBM-bound sort is enqueued beside the VALU-bound stage-3 search (st_aux / st_hi)
     int device;  // HIP device the context lives on; every entry point re-selects it (callers may use any thread)
     std::vector<StreamState> ss;
     std::vector<void *> allocs;
@@ -165,8 +167,9 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     }
     ferhip_ctx *c = new ferhip_ctx();
     memset(&c->d, 0, sizeof c->d);
-    c->st = c->st_hi = nullptr;
-    c->ev_a = c->ev_b = nullptr;
+    c->st = c->st_hi = c->st_aux = nullptr;
+    c->ev_a = c->ev_b = c->ev_c = c->ev_d = nullptr;
+    c->overlap_sort = 0;  // measured: kernels of two HIP streams do not share the GPU here (the sort stretches to k_me_pre's length)
     c->h_hdr = c->h_hdr_ring = c->h_len = nullptr;
     c->h_status = nullptr;
     c->h_sad = nullptr;
@@ -208,12 +211,15 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     d.ysz = (size_t)W * H;
     d.csz = d.ysz / 4;
     d.resolve_wgs = 6144;
-    d.resolve_group = 16;
+    d.resolve_group = S < 32 ? S : 32;
     {
         int lo = 0, hi = 0;  // numerically lower = higher priority
         if (hipGetDevice(&c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
             hipStreamCreateWithPriority(&c->st, hipStreamNonBlocking, lo) != hipSuccess ||
             hipStreamCreateWithPriority(&c->st_hi, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&c->st_aux, hipStreamNonBlocking, lo) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_c, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_d, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess) {
             ferhip_destroy(c);
@@ -332,6 +338,7 @@ extern "C" void ferhip_destroy(ferhip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->st) hipStreamSynchronize(c->st);
     if (c->st_hi) hipStreamSynchronize(c->st_hi);
+    if (c->st_aux) hipStreamSynchronize(c->st_aux);
     for (void *p : c->allocs) hipFree(p);
     if (c->h_hdr_ring) hipHostFree(c->h_hdr_ring);
     for (int i = 0; i < FER_HDR_SLOTS; i++)
@@ -349,6 +356,9 @@ extern "C" void ferhip_destroy(ferhip_ctx *c)
     }
     if (c->st) hipStreamDestroy(c->st);
     if (c->st_hi) hipStreamDestroy(c->st_hi);
+    if (c->st_aux) hipStreamDestroy(c->st_aux);
+    if (c->ev_c) hipEventDestroy(c->ev_c);
+    if (c->ev_d) hipEventDestroy(c->ev_d);
     if (c->ev_a) hipEventDestroy(c->ev_a);
     if (c->ev_b) hipEventDestroy(c->ev_b);
     delete c;
@@ -736,6 +746,10 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
     if (hdr_upload(c)) return FERHIP_E_HIP;
     const int ndiag = d.mbw + 2 * (d.mbh - 1);
     if (anyP) {
+        // The radix sort of the reference picture's positions and its bucket index are a stream of HBM traffic that only
+        // the bucket walk needs; the stage-3 search (k_me_pre) is bound by VALU issue and needs only the quarter-sample
+        // planes and the plane-0 features.  The two run side by side: the sort on st_aux, k_me_pre on st.
+        bool sort_aside = false;
         if (!c->refprep_valid) {
             {
                 ProfScope ps(c, FERHIP_PH_INTERP, 1);
@@ -747,20 +761,29 @@ static int run_picture(ferhip_ctx *c, int *nal_type)
                     ProfScope ps(c, FERHIP_PH_SORT_KEYS, 1);
                     fer_launch_sort_keys(d, c->sort, c->st);
                 }
-                {
-                    ProfScope ps(c, FERHIP_PH_SORT, 1);
-                    fer_launch_sort_radix(d, c->sort, c->st);
+                hipStream_t ss = c->st;
+                if (c->overlap_sort) {
+                    sort_aside = true;
+                    ss = c->overlap_sort == 2 ? c->st_hi : c->st_aux;
+                    CK(hipEventRecord(c->ev_c, c->st));
+                    CK(hipStreamWaitEvent(ss, c->ev_c, 0));
                 }
                 {
-                    ProfScope ps(c, FERHIP_PH_SORT_FINISH, 1);
-                    fer_launch_sort_finish(d, c->sort, c->st);
+                    ProfScope ps(c, FERHIP_PH_SORT, 1, ss);
+                    fer_launch_sort_radix(d, c->sort, ss);
                 }
+                {
+                    ProfScope ps(c, FERHIP_PH_SORT_FINISH, 1, ss);
+                    fer_launch_sort_finish(d, c->sort, ss);
+                }
+                if (sort_aside) CK(hipEventRecord(c->ev_d, ss));
             }
         }
         {
             ProfScope ps(c, FERHIP_PH_ME_PRE, 1);
             fer_launch_me_pre(d, c->st);
         }
+        if (sort_aside) CK(hipStreamWaitEvent(c->st, c->ev_d, 0));
         {
             ProfScope ps(c, FERHIP_PH_ME_WALK, 1);
             fer_launch_me_walk(d, c->st);
@@ -921,6 +944,8 @@ static hipError_t ctx_sync(ferhip_ctx *c)
 {
     hipError_t e = hipStreamSynchronize(c->st);
     if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(c->st_aux);
+    if (e != hipSuccess) return e;
     return hipStreamSynchronize(c->st_hi);
 }
 
@@ -954,6 +979,10 @@ extern "C" int ferhip_tune(ferhip_ctx *c, int key, int value)
     case FERHIP_TUNE_RESOLVE_GROUP:
         if (value < 1) return FERHIP_E_ARG;
         c->d.resolve_group = value < c->d.S ? value : c->d.S;  // (more streams than the context has add nothing)
+        return 0;
+    case FERHIP_TUNE_OVERLAP_SORT:
+        if (value < 0 || value > 2) return FERHIP_E_ARG;  // (2: on the high-priority stream -- an experiment)
+        c->overlap_sort = value;
         return 0;
     case FERHIP_TUNE_SPECULATE:
         if (value != 0 && value != 1) return FERHIP_E_ARG;

@@ -85,12 +85,13 @@ __device__ __forceinline__ void wl_insert(WList &L, int K, int lane, bool valid,
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
         __builtin_amdgcn_wave_barrier();                   \
     } while (0)
-__device__ __forceinline__ int lds_rank64(const unsigned *p, unsigned mine)
+__device__ __forceinline__ int lds_rank64(const unsigned *p, unsigned mine, int n4 = 16)
 {
+    // n4 = how many groups of four slots hold keys (wave-uniform); the slots behind them are 0xffffffff, below nothing
     const uint4 *q = (const uint4 *)p;
     int r = 0;
 #pragma unroll 4
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < n4; i++) {
         uint4 k = q[i];
         r += (int)(k.x < mine) + (int)(k.y < mine) + (int)(k.z < mine) + (int)(k.w < mine);
     }
@@ -156,7 +157,7 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
         WAVE_LDS_SYNC();
         const unsigned mine = B[lane];
         const int mypay = Ci[lane];
-        const int rk = lds_rank64(B, mine);
+        const int rk = lds_rank64(B, mine, (__builtin_amdgcn_readfirstlane(c) + 3) >> 2);  // (only the c survivors are keys)
         WAVE_LDS_SYNC();
         if (lane < c && rk < need) {
             A[rk] = mine >> 11;
@@ -307,7 +308,7 @@ __device__ __forceinline__ FeatRec feat_rec_direct(const IPlanes &ip, int W, int
         const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], sh), hi = __builtin_amdgcn_alignbyte(w[2], w[1], sh);
         const uint32_t a4 = __builtin_amdgcn_sad_u8(lo, 0u, 0u);
         h84[r] = __builtin_amdgcn_sad_u8(hi, 0u, a4) | (a4 << 16);
-        hc[r] = __builtin_amdgcn_sad_u8(hi & 0xffffu, 0u, __builtin_amdgcn_sad_u8(lo & 0xffffu, 0u, 0u));
+        hc[r] = __builtin_amdgcn_udot4(hi, 0x00000101u, __builtin_amdgcn_udot4(lo, 0x00000101u, 0u, false), false);
     }
     const uint32_t top = h84[0] + h84[1] + h84[2] + h84[3], all = top + h84[4] + h84[5] + h84[6] + h84[7];
     const uint32_t k3 = (h84[0] + h84[1] + h84[4] + h84[5]) & 0xffffu;
@@ -372,7 +373,7 @@ __device__ __forceinline__ void local_metrics(const IPlanes &ip, int W, int H, i
                     const uint32_t hi = ix < 4 ? __builtin_amdgcn_alignbyte(b2, b1, (uint32_t)(ix & 3)) : b2;
                     const uint32_t a4 = __builtin_amdgcn_sad_u8(lo, 0u, 0u);
                     o[ix * 2] = __builtin_amdgcn_sad_u8(hi, 0u, a4) | (a4 << 16);
-                    o[ix * 2 + 1] = __builtin_amdgcn_sad_u8(hi & 0xffffu, 0u, __builtin_amdgcn_sad_u8(lo & 0xffffu, 0u, 0u));
+                    o[ix * 2 + 1] = __builtin_amdgcn_udot4(hi, 0x00000101u, __builtin_amdgcn_udot4(lo, 0x00000101u, 0u, false), false);  // samples {0,1,4,5}
                 }
             }
         }
@@ -1229,6 +1230,21 @@ struct ResNbr {      // neighbour vectors of one partition (packed), v* = availa
     int A, B, C, D, C16;
 };
 
+// Availability of the neighbours of the 8x8 partition (gx, gy) in PARTITION coordinates (F/mode_pred.cpp:60-110 for 8x8
+// partitions of inter macroblocks): B = (gx, gy - 1), C = (gx + 1, gy - 1), D = (gx - 1, gy - 1), and for the 16x16
+// (P_Skip) predictor of partition 0 C16 = (gx + 2, gy - 1).  C does not exist for partition 3 (not yet decoded) and
+// always for partition 2 (the macroblock's own quadrant 1); everything is wave-uniform.
+__device__ __forceinline__ void nbr_avail(int gx, int gy, int gw, bool &vB, bool &vC, bool &vD, bool &vC16)
+{
+    const int part = (gy & 1) * 2 + (gx & 1);
+    vB = gy > 0;
+    vD = gy > 0 && gx > 0;
+    vC = part == 3 ? false : (part == 2 ? true : (part == 1 ? (gy > 0 && gx + 1 < gw) : gy > 0));
+    vC16 = part == 0 && gy > 0 && gx + 2 < gw;
+}
+// index of partition (xa, ya) in an array laid out [macroblock][quadrant]
+__device__ __forceinline__ int part_slot(int mbw, int xa, int ya) { return (((ya >> 1) * mbw + (xa >> 1)) << 2) + ((ya & 1) << 1) + (xa & 1); }
+
 __device__ __forceinline__ void nbr_to(int v, bool ok, int &mx, int &my, int &ref)
 {
     mx = ok ? (int)(short)(v & 0xffff) : FER_MV_NA;
@@ -1575,24 +1591,13 @@ __device__ __forceinline__ void resolve_stage23(const FerDev &d, int s, int gx, 
 // neighbour vectors of partition (gx, gy) out of a per-stream array of packed vectors [nmb][4] (the guesses v0)
 __device__ __forceinline__ ResNbr nbr_from_field(const FerDev &d, const int *vf, int gx, int gy, int lane)
 {
-    const int part = (gy & 1) * 2 + (gx & 1), mbx = gx >> 1, mby = gy >> 1;
-    const int x = (part & 1) * 8, y = (part >> 1) * 8;
-    bool val = false;
-    int mbN = 0, q = 0;
-    // lane 0 = B, 1 = C, 2 = D, 3 = C of the 16x16 (P_Skip) predictor, 4 = A
-    if (lane < 5 && (lane != 3 || part == 0)) {
-        const int nx = lane == 0 ? x : (lane == 1 ? x + 8 : (lane == 3 ? 16 : x - 1));
-        const int ny = lane == 3 ? -1 : (lane == 4 ? y : y - 1);
-        nbr_locate_xy(d.mbw, mbx, mby, nx, ny, val, mbN, q);
-    }
-    const int w = val ? vf[(size_t)mbN * 4 + q] : 0;
-    const unsigned long long vm = __ballot(val);
     ResNbr N;
-    N.vB = vm & 1;
-    N.vC = (vm >> 1) & 1;
-    N.vD = (vm >> 2) & 1;
-    N.vC16 = (vm >> 3) & 1;
-    N.vA = (vm >> 4) & 1;
+    nbr_avail(gx, gy, d.mbw * 2, N.vB, N.vC, N.vD, N.vC16);
+    N.vA = gx > 0;
+    // lane 0 = B, 1 = C, 2 = D, 3 = C of the 16x16 (P_Skip) predictor, 4 = A
+    const int xa = gx + (lane == 0 ? 0 : (lane == 1 ? 1 : (lane == 2 ? -1 : (lane == 3 ? 2 : -1)))), ya = lane == 4 ? gy : gy - 1;
+    const bool val = lane == 0 ? N.vB : (lane == 1 ? N.vC : (lane == 2 ? N.vD : (lane == 3 ? N.vC16 : (lane == 4 && N.vA))));
+    const int w = val ? vf[part_slot(d.mbw, xa, ya)] : 0;
     N.B = lane_bcast(w, 0);
     N.C = lane_bcast(w, 1);
     N.D = lane_bcast(w, 2);
@@ -1677,27 +1682,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC_WAVES,
     if (lane == 0) d.spec_hdr[pidx] = make_int4(genw, cnt1 | (cnt2 << 8) | (1 << 16) | (part == 0 ? (1 << 17) : 0), smw, 0);
 }
 
-__device__ __forceinline__ void res_spec_load(const FerDev &d, bool spec, size_t pidx, int ln, int4 &sh, int2 &e1, int2 &e2, int &c3x, int &c3y,
-                                              int &c3s, int &n3)
-{
-    sh = make_int4(0, 0, 0, 0);
-    e1 = e2 = make_int2(0, 0);
-    c3x = c3y = c3s = n3 = 0;
-    if (FER_DBGF(d, 512)) pidx &= 1023;  // (probe: the chain with its list reads served from cache)
-    if (spec) {
-        sh = d.spec_hdr[pidx];
-        e1 = d.spec_l1[pidx * 17 + min(ln, 16)];
-        e2 = d.spec_l2[pidx * 33 + min(ln, 32)];
-        if (!d.basic) {
-            const int *c3 = d.st3 + (pidx * 33 + min(ln, 32)) * 3;
-            c3x = c3[0];
-            c3y = c3[1];
-            c3s = c3[2];
-            n3 = d.st3n[pidx];
-        }
-    }
-}
-
 #ifndef RES_WIN
 #define RES_WIN 16  // steps between two loads of the window over the row above (a power of two, RES_WIN + 3 <= 64)
 #endif
@@ -1765,21 +1749,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RES_WAVES, R
     bool skip = false, timeout = false;
     unsigned cwl = 0, cwh = 0;  // the window over the row above: lane l = partition wbase + l
     int wbase = 0;
+    const size_t pidx0 = ((size_t)s * d.nmb + (size_t)(gy >> 1) * d.mbw) * 4 + (size_t)(gy & 1) * 2;  // partition (0, gy)
+    const int4 *row_hdr = d.spec_hdr + pidx0;
+    const int2 *row_l1 = d.spec_l1 + pidx0 * 17, *row_l2 = d.spec_l2 + pidx0 * 33;
+    const int *row_st3 = d.st3 + pidx0 * 33 * 3, *row_st3n = d.st3n + pidx0;
     for (int gx = 0; gx < gw; gx++) {
         if (probe) tmark = wall_clock64();
         const int part = (gy & 1) * 2 + (gx & 1);
         const int mbx = gx >> 1, mby = gy >> 1;
         const int mb = mby * d.mbw + mbx;
-        const size_t pidx = ((size_t)s * d.nmb + mb) * 4 + part;
         // the lane id is made opaque per iteration: otherwise dozens of lane-derived constants of the loop body
         // are hoisted out of the loop and spilled
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        // what the guessed search left behind: the lane's entry of either list and of the stage-3 survivors
-        int4 sh;
-        int2 e1, e2;
-        int c3x, c3y, c3s, n3;
-        res_spec_load(d, spec, pidx, ln, sh, e1, e2, c3x, c3y, c3s, n3);
+        // what the guessed search left behind: the lane's entry of either list and of the stage-3 survivors (addressed
+        // relative to the row's first partition: 32-bit offsets per step, the 64-bit bases once per row)
+        int4 sh = make_int4(0, 0, 0, 0);
+        int2 e1 = make_int2(0, 0), e2 = make_int2(0, 0);
+        int c3x = 0, c3y = 0, c3s = 0, n3 = 0;
+        if (spec) {
+            const unsigned rp = (FER_DBGF(d, 512) ? 0u : (unsigned)((gx >> 1) * 4 + (gx & 1)));  // (probe: list reads served from cache)
+            sh = row_hdr[rp];
+            e1 = row_l1[rp * 17u + (unsigned)min(ln, 16)];
+            e2 = row_l2[rp * 33u + (unsigned)min(ln, 32)];
+            if (!d.basic) {
+                const int *c3 = row_st3 + (rp * 33u + (unsigned)min(ln, 32)) * 3u;
+                c3x = c3[0];
+                c3y = c3[1];
+                c3s = c3[2];
+                n3 = row_st3n[rp];
+            }
+        }
         // A window over the row above: every RES_WIN steps ONE 64-lane load fetches the words of the partitions gx - 1 ...
         // gx + 62 of that row; the four a step needs come out of it with two ds_bpermute.  A word that was not valid when
         // the window was loaded (the row above was not that far ahead) is polled for.  (Agent-scope loads cross the
@@ -1788,27 +1788,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RES_WAVES, R
             wbase = gx - 1;
             const int xa = wbase + ln;
             unsigned long long w = 0;
-            if (gy > 0 && xa >= 0 && xa < gw)
-                w = __hip_atomic_load(chw + ((size_t)(((gy - 1) >> 1) * d.mbw + (xa >> 1)) * 4 + (((gy - 1) & 1) * 2 + (xa & 1))), __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);
+            if (gy > 0 && xa >= 0 && xa < gw) w = __hip_atomic_load(chw + part_slot(d.mbw, xa, gy - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             cwl = (unsigned)w;
             cwh = (unsigned)(w >> 32);
         }
-        // neighbours in the row above: lane 0 = B, 1 = C, 2 = D, 3 = C of the 16x16 (P_Skip) predictor
-        const int x = (part & 1) * 8, y = (part >> 1) * 8;
-        bool val = false;
-        int mbN = 0, q = 0;
-        if (ln < 3 || (ln == 3 && part == 0)) {
-            int nx = ln == 0 ? x : (ln == 1 ? x + 8 : (ln == 2 ? x - 1 : 16));
-            int ny = ln == 3 ? -1 : y - 1;
-            nbr_locate_xy(d.mbw, mbx, mby, nx, ny, val, mbN, q);
-        }
-        const int widx = gx - wbase + (ln == 0 ? 0 : (ln == 1 ? 1 : (ln == 2 ? -1 : 2)));  // B, C, D, C16 sit at gx, gx + 1, gx - 1, gx + 2
-        unsigned wl = (unsigned)__shfl((int)cwl, widx & 63), wh = (unsigned)__shfl((int)cwh, widx & 63);
+        // neighbours in the row above: lane 0 = B, 1 = C, 2 = D, 3 = C of the 16x16 (P_Skip) predictor -- the partitions
+        // gx, gx + 1, gx - 1, gx + 2 of row gy - 1; which of them exist is wave-uniform (nbr_avail)
+        ResNbr N;
+        nbr_avail(gx, gy, gw, N.vB, N.vC, N.vD, N.vC16);
+        // (bit tricks instead of per-lane selects of wave-uniform booleans, which compile to exec-mask branches)
+        const unsigned vmask = (N.vB ? 1u : 0u) | (N.vC ? 2u : 0u) | (N.vD ? 4u : 0u) | (N.vC16 ? 8u : 0u);
+        const int noff = (int)((0x3021u >> ((ln & 3) * 4)) & 15u) - 1;  // 0, +1, -1, +2 for lanes 0..3
+        const bool val = ln < 4 && ((vmask >> (ln & 3)) & 1u) != 0;
+        unsigned wl = (unsigned)__shfl((int)cwl, (gx + noff - wbase) & 63), wh = (unsigned)__shfl((int)cwh, (gx + noff - wbase) & 63);
         bool ok = !val || (wh & 0x7fffffffu) == serial;
         for (int it = 0; !__all(ok); it++) {
             if (val && !ok) {
-                unsigned long long w = __hip_atomic_load(chw + (size_t)mbN * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long w = __hip_atomic_load(chw + part_slot(d.mbw, gx + noff, gy - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 wl = (unsigned)w;
                 wh = (unsigned)(w >> 32);
                 ok = (wh & 0x7fffffffu) == serial;
@@ -1821,14 +1817,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RES_WAVES, R
             __builtin_amdgcn_s_sleep(2);
         }
         PR_MARK(0)
-        ResNbr N;
-        const unsigned long long vm = __ballot(val);
         N.vA = gx > 0;
         N.A = prevw;
-        N.vB = vm & 1;
-        N.vC = (vm >> 1) & 1;
-        N.vD = (vm >> 2) & 1;
-        N.vC16 = (vm >> 3) & 1;
         N.B = lane_bcast((int)wl, 0);
         N.C = lane_bcast((int)wl, 1);
         N.D = lane_bcast((int)wl, 2);

@@ -9,7 +9,7 @@ NAL_SLICE, NAL_IDR, NAL_AUTO = 1, 5, 0
 
 BUF = dict(INTERP=1, FEAT=2, SORTPOS=3, KOLIKO=4, MBTYPE=5, MV=6, MVD=7, LEVELS=8, CBP=9, TC=10, I4MODE=11,
            CUR=12, REF=13, TIMING=14, ST2N=15, ST2=16, SPEC_STAT=17, MBSIZE=18)
-TUNE_RESOLVE_WGS, TUNE_RESOLVE_GROUP, TUNE_SPECULATE = 1, 2, 3
+TUNE_RESOLVE_WGS, TUNE_RESOLVE_GROUP, TUNE_SPECULATE, TUNE_OVERLAP_SORT = 1, 2, 3, 4
 _BUF_DTYPE = {1: np.uint8, 2: np.uint16, 3: np.uint32, 4: np.int32, 5: np.int32, 6: np.int16, 7: np.int16,
               8: np.int16, 9: np.uint8, 10: np.uint8, 11: np.uint8, 12: np.uint8, 13: np.uint8, 14: np.int64, 15: np.int32, 16: np.int32,
               17: np.uint64, 18: np.int32}

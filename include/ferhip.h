@@ -140,6 +140,9 @@ int ferhip_profile(ferhip_ctx *c, int enable);
  * (default 6144 single-wavefront workgroups; any value >= 1 resolves every row: a workgroup whose own queue is empty takes rows of the others) */
 #define FERHIP_TUNE_RESOLVE_WGS 1
 #define FERHIP_TUNE_RESOLVE_GROUP 2 /* streams whose rows the motion chain keeps in flight together (cache footprint); clamped to the context's streams */
+#define FERHIP_TUNE_OVERLAP_SORT 4  /* 0 (default): the radix sort + bucket index of the reference picture run before k_me_pre; 1 / 2: on a
+                                       second stream beside it (measured on MI355X / ROCm 7.2: the two launches do not share the
+                                       GPU, the sort simply ends later -- kept as an experiment switch) */
 #define FERHIP_TUNE_SPECULATE 3     /* 1 (default): k_me_spec runs the predictor-dependent searches for a guessed predictor and the
                                        chain verifies; 0: the chain searches everything itself */
 int ferhip_tune(ferhip_ctx *c, int key, int value);

@@ -4,7 +4,7 @@ cp h264-fer_amd/libferhip.so /tmp/libferhip_keep.so
 for v in $1; do
   cp h264-fer_amd/var/libferhip_$v.so h264-fer_amd/libferhip.so
   for g in $2; do
-    python bench.py --streams 128 --contexts 1 --steps 1 --warmup 1 --cpu-frames 0 --secondary 0 --e2e 0 --resolve-group $g $3 > gpurun_out/ab_${v}_g$g.json 2> gpurun_out/ab_${v}_g$g.err || echo "FAILED $v $g"
+    python bench.py --streams 256 --contexts 1 --steps 1 --warmup 1 --cpu-frames 0 --secondary 0 --e2e 0 --resolve-group $g $3 > gpurun_out/ab_${v}_g$g.json 2> gpurun_out/ab_${v}_g$g.err || echo "FAILED $v $g"
   done
 done
 cp /tmp/libferhip_keep.so h264-fer_amd/libferhip.so
