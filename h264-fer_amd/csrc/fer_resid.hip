@@ -25,7 +25,10 @@
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
         __builtin_amdgcn_wave_barrier();                       \
     } while (0)
-__global__ __launch_bounds__(256) void k_p_resid(FerDev d)
+#ifndef RESID_WAVES
+#define RESID_WAVES 6  // 74 registers, no scratch; the kernel is a chain of memory round trips and gains from the sixth wavefront
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RESID_WAVES, 8))) void k_p_resid(FerDev d)
 {
     __shared__ __align__(16) int16_t lvs_[4][FER_LEVELS];
     __shared__ __align__(4) uint8_t tcs_[4][24];
