@@ -1717,7 +1717,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RES_WAVES, R
     int t = 0;
     if (lane == 0) t = atomicAdd(d.chain + qu, 1);
     t = __builtin_amdgcn_readfirstlane(t);
-    const int G = d.resolve_group;
+    const int G = min(d.resolve_group, nsq);  // (a group larger than the queue would only mint tickets that name no row)
     const int grp = t / (gh * G), rr = t - grp * (gh * G);
     const int k0 = grp * G, kn = min(G, nsq - k0);  // streams of this group, as indices into the queue's stream list
     if (k0 >= nsq) {
