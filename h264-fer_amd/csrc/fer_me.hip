@@ -71,7 +71,7 @@ __device__ __forceinline__ void wl_insert(WList &L, int K, int lane, bool valid,
 // wavefront runs alone on its SIMD and every dependent instruction costs its full latency, so
 // it is built from few, wide steps:
 //   1. T0 = the need-th smallest per-lane minimum -- an upper bound of the need-th smallest
-//      candidate (one rank computation over 64 LDS words),
+//      candidate (binary search over the value with ballot counts: scalar work),
 //   2. the candidates <= T0 (typically 1.2-1.5 x need of them) are gathered in LDS, in no particular order,
 //   3. their exact rank by (metric << 11 | arrival index) places the winners.
 // More than 64 survivors of step 2 or a T0 >= 2^21 take the binary-search route instead.
@@ -119,18 +119,28 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
     if (need == 0) return;
     int c = 65;
     if (!__any(lmax >= (1 << 26))) {
-        const unsigned mykey = lmin != 0x7fffffff ? ((unsigned)lmin << 6) | (unsigned)lane : 0xffffffffu;
-        A[lane] = mykey;
         B[lane] = 0xffffffffu;
         if (lane == 0) Di[63] = 0;  // slot counter of the compaction below (Di[0 .. need-1] are written much later)
-        WAVE_LDS_SYNC();
-        const int rk = lds_rank64(A, mykey);
-        const unsigned long long hit = __ballot(rk == need - 1);
+        // T0 = the need-th smallest per-lane minimum -- an upper bound of the need-th smallest candidate -- by binary search
+        // over the value: one compare and one scalar population count per step.  (A rank computation over the 64 minima
+        // through LDS cost 130 vector instructions here; these kernels are bound by vector issue, the scalar unit has room.)
         int T0 = 0x7fffffff;  // fewer than `need` lanes hold anything: every candidate is needed
-        if (hit) {
-            unsigned tk = (unsigned)lane_bcast((int)mykey, __ffsll((long long)hit) - 1);
-            if (tk != 0xffffffffu) T0 = (int)(tk >> 6);
+        if (__popcll(__ballot(lmin != 0x7fffffff)) >= need) {
+            int lo = 0, hi = (1 << 21) - 1;
+            if (__popcll(__ballot(lmin <= hi)) >= need) {
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (__popcll(__ballot(lmin <= mid)) >= need)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                T0 = lo;
+            } else {
+                T0 = 1 << 21;  // the general route below
+            }
         }
+        WAVE_LDS_SYNC();
         // The candidates <= T0 are gathered in NO particular order (an LDS counter hands out the slots, batches
         // without survivors cost a compare and a branch); what orders them is the key metric << 11 | arrival index,
         // exact as long as the survivors' metrics stay below 2^21 (they are the smallest ones; larger takes the
@@ -333,11 +343,43 @@ struct LocalGeo {
     static constexpr int N1 = 2 * R1 + 1, PW = 2 * R1 + 8, NC = N1 * N1 * 16, NB = (NC + 63) / 64;
     static constexpr int HTAB = 8 * PW * N1 * 2;
 };
-// half_lo .. half_hi: which groups of 8 planes this call computes (k_me_resolve splits them over its two wavefronts, each
-// with its own htab; the caller orders the shared mtab).
+// The 16-byte patch rows of all 16 planes, requested ahead of their use: row task t = t0 + lane of either group of 8 planes
+// (two rounds of 64 tasks per group).  A caller that knows the search centre early (k_me_spec, k_me_pre) issues these loads
+// before it waits for anything else, so that their round trip overlaps the ones in front of the search.
+template <int R1>
+struct LocalLoads {
+    static constexpr int ROUNDS = (8 * LocalGeo<R1>::PW + 63) / 64;
+    uint4 w[2][ROUNDS];
+};
+template <int R1>
+__device__ __forceinline__ void local_request(const IPlanes &ip, int W, int H, int px0, int py0, int lane, LocalLoads<R1> &ld)
+{
+    using G = LocalGeo<R1>;
+    constexpr int N1 = G::N1, PW = G::PW;
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+#pragma unroll
+        for (int k = 0; k < LocalLoads<R1>::ROUNDS; k++) ld.w[half][k] = make_uint4(0, 0, 0, 0);
+    if (px0 + N1 - 1 < 0 || px0 >= W || py0 + N1 - 1 < 0 || py0 >= H) return;
+    const uint8_t *mbase = ip.base - ((size_t)FER_IP_T * ip.pitch + FER_IP_L);
+    const uint32_t obase = __umul24((uint32_t)(py0 + FER_IP_T), (uint32_t)ip.pitch) + (uint32_t)((px0 & ~3) + FER_IP_L);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+#pragma unroll
+        for (int k = 0; k < LocalLoads<R1>::ROUNDS; k++) {
+            const int tt = min(k * 64 + lane, 8 * PW - 1);
+            const int fl = tt / PW, r = tt - fl * PW;
+            typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            const u32x4_a4 v = *(const u32x4_a4 *)(mbase + (obase + __umul24((uint32_t)(half * 8 + fl), (uint32_t)ip.plane) + __umul24((uint32_t)r, (uint32_t)ip.pitch)));
+            ld.w[half][k] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    }
+}
+// half_lo .. half_hi: which groups of 8 planes this call computes (two wavefronts may split them, each with its own htab; the
+// caller orders the shared mtab).  pre: the patch rows requested earlier with local_request (all 16 planes), or null.
 template <int R1>
 __device__ __forceinline__ void local_metrics(const IPlanes &ip, int W, int H, int px0, int py0, const SuPk &sp, int lane,
-                                              uint32_t *htab, int *mtab, int half_lo = 0, int half_hi = 2)
+                                              uint32_t *htab, int *mtab, int half_lo = 0, int half_hi = 2, const LocalLoads<R1> *pre = nullptr)
 {
     using G = LocalGeo<R1>;
     constexpr int N1 = G::N1, PW = G::PW;
@@ -362,7 +404,13 @@ __device__ __forceinline__ void local_metrics(const IPlanes &ip, int W, int H, i
             const int tt = min(t, 8 * PW - 1);
             const int fl = tt / PW, r = tt - fl * PW;
             typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-            const u32x4_a4 w = *(const u32x4_a4 *)(mbase + (obase + __umul24((uint32_t)(half * 8 + fl), (uint32_t)ip.plane) + __umul24((uint32_t)r, (uint32_t)ip.pitch)));
+            uint4 w;
+            if (pre) {
+                w = half == 0 ? pre->w[0][t0 / 64] : pre->w[1][t0 / 64];
+            } else {
+                const u32x4_a4 v = *(const u32x4_a4 *)(mbase + (obase + __umul24((uint32_t)(half * 8 + fl), (uint32_t)ip.plane) + __umul24((uint32_t)r, (uint32_t)ip.pitch)));
+                w = make_uint4(v.x, v.y, v.z, v.w);
+            }
             const uint32_t b0 = __builtin_amdgcn_alignbyte(w.y, w.x, sh), b1 = __builtin_amdgcn_alignbyte(w.z, w.y, sh),
                            b2 = __builtin_amdgcn_alignbyte(w.w, w.z, sh);
             if (t < 8 * PW) {
@@ -1636,6 +1684,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC_WAVES,
     int *mtab = (int *)loc_all[part] + LocalGeo<2>::HTAB;
     int *sel_lds = (int *)loc_all[part];  // the row sums are dead when the selections start
     const ResNbr N = nbr_from_field(d, d.v0 + (size_t)s * d.nmb * 4, gx, gy, lane);
+    int mvpx, mvpy;
+    predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
+    const int genx = mvpx >> 2, geny = mvpy >> 2;
+    const int genw = pack_xy(genx, geny);
+    const int W = d.W, H = d.H;
+    const IPlanes ip = ip_stream(d, s);
+    const int sx = gx * 8, sy = gy * 8;
+    // everything the searches will read is requested now, in front of the P_Skip test and its barrier: the launch is bound by
+    // the latency of its wavefronts (a chain of memory round trips), not by how many instructions it issues
+    constexpr int RRL = (WIN == 16) ? 1 : 2;
+    LocalLoads<RRL> ld;
+    if (WIN == 32 || WIN == 16) local_request<RRL>(ip, W, H, sx + genx - RRL, sy + geny - RRL, lane, ld);
     ResPre P;
     res_prefetch(d, s, gx, gy, lane, 1, P);
     int smw = 0;
@@ -1649,35 +1709,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC_WAVES,
     }
     __syncthreads();
     sk = skipflag != 0;
-    int mvpx, mvpy;
-    predict_nbr(N.vA, N.A, N.vB, N.B, N.vC, N.C, N.vD, N.D, mvpx, mvpy);
-    const int genx = mvpx >> 2, geny = mvpy >> 2;
-    const int genw = pack_xy(genx, geny);
     if (sk) {  // no lists: if the chain finds the macroblock is not skipped after all, it searches itself
         if (lane == 0) d.spec_hdr[pidx] = make_int4(genw, part == 0 ? (1 << 17) : 0, smw, 1);
         return;
     }
-    const int W = d.W, H = d.H;
-    const IPlanes ip = ip_stream(d, s);
-    const int sx = gx * 8, sy = gy * 8;
-    if (WIN == 32 || WIN == 16) {
-        constexpr int RR = (WIN ? WIN : 32) / 16;
-        local_metrics<RR>(ip, W, H, sx + genx - RR, sy + geny - RR, su_pack(P.su), lane, htab, mtab);
-    }
+    if (WIN == 32 || WIN == 16) local_metrics<RRL>(ip, W, H, sx + genx - RRL, sy + geny - RRL, su_pack(P.su), lane, htab, mtab, 0, 2, &ld);
     WList L1, L2;
     const int cnt1 = stage1_list<WIN>(d, s, gx, gy, lane, P, genx, geny, sel_lds, mtab, L1);
-    {
-        const bool on = lane < cnt1;
-        const int cx = on ? unp_x(L1.xy) : 0, cy = on ? unp_y(L1.xy) : 0;
-        const int sad = sad_lane(ip, W, H, sx, sy, cx, cy, P.sb);
-        if (on) d.spec_l1[pidx * 17 + lane] = make_int2(L1.xy, sad);
-    }
     const int cnt2 = stage2_list(d, s, gx, gy, lane, P, genx, geny, sel_lds, L2);
     {
-        const bool on = lane < cnt2;
-        const int cx = on ? unp_x(L2.xy) : 0, cy = on ? unp_y(L2.xy) : 0;
+        // ONE pass of SADs for both lists: the 17 stage-1 candidates in lanes 0 .. 16, the 33 stage-2 candidates in lanes
+        // 17 .. 49 (one memory round trip instead of two: the launch is bound by the latency of its wavefronts)
+        const int xy2 = __shfl(L2.xy, (lane - 17) & 63);
+        const bool first = lane < 17;
+        const int xy = first ? L1.xy : xy2;
+        const bool on = first ? lane < cnt1 : (lane - 17 < cnt2 && lane < 50);
+        const int cx = on ? unp_x(xy) : 0, cy = on ? unp_y(xy) : 0;
         const int sad = sad_lane(ip, W, H, sx, sy, cx, cy, P.sb);
-        if (on) d.spec_l2[pidx * 33 + lane] = make_int2(L2.xy, sad);
+        if (on) {
+            int2 *o = first ? d.spec_l1 + (pidx * 17 + lane) : d.spec_l2 + (pidx * 33 + (lane - 17));
+            *o = make_int2(xy, sad);
+        }
     }
     if (lane == 0) d.spec_hdr[pidx] = make_int4(genw, cnt1 | (cnt2 << 8) | (1 << 16) | (part == 0 ? (1 << 17) : 0), smw, 0);
 }
