@@ -556,6 +556,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PRE_WAVES, P
 #else
 #define PP_MARK(k)
 #endif
+    // the patch rows of the local search are requested before anything is waited for (their addresses depend on the
+    // position only)
+    constexpr int RRL = (WIN == 16) ? 1 : 2;
+    LocalLoads<RRL> ld;
+    const bool fast_path = (WIN == 32 || WIN == 16) && !FER_DBGF(d, 3) && !d.basic;
+    if (fast_path) local_request<RRL>(ip, W, H, sx - RRL, sy - RRL, lane, ld);
     // box sums of the source block, F/moestimation.cpp:440-451
     int px = lane & 7, py = lane >> 3;
     int v = Y[(size_t)(sy + py) * W + sx + px];
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PRE_WAVES, P
     const int wb = (n * n + 63) >> 6;  // batches of the wide search
     if ((WIN == 32 || WIN == 16) && !FER_DBGF(d, 3)) {
         // the local search first (its row sums borrow the LDS of the wide search's metrics)
-        local_metrics<(WIN ? WIN : 32) / 16>(ip, W, H, sx - r2, sy - r2, sp, lane, (uint32_t *)wide_m, sel_lds);
+        local_metrics<RRL>(ip, W, H, sx - r2, sy - r2, sp, lane, (uint32_t *)wide_m, sel_lds, 0, 2, &ld);
         // pass A: lanes run along x (contiguous 12-byte records); metrics land in LDS at their
         // arrival index (tx outer, ty inner).  Records are fetched six batches at a time with
         // clamped coordinates (no control flow around the loads), then masked.
@@ -602,8 +608,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PRE_WAVES, P
             // (32-bit byte offsets from the stream's uniform base: a record load is one instruction with a scalar base,
             // where 64-bit index arithmetic costs nine VALU instructions per load)
             const uint32_t colo = (uint32_t)iclamp(rx, 0, W - 1) * 12u, rowb = (uint32_t)W * 12u;
-            for (int iy0 = 0; iy0 < n; iy0 += RPB * WCH) {
-                FeatRec fr[WCH];
+            // the records of the next six batches are in flight while the current six are evaluated
+            auto wide_load = [&](int iy0, FeatRec (&fr)[WCH]) {
 #pragma unroll
                 for (int q = 0; q < WCH; q++) {
                     int ry = iclamp(sy - R + iy0 + q * RPB + r0, 0, H - 1);
@@ -612,6 +618,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PRE_WAVES, P
                     fr[q].b = r[1];
                     fr[q].c = r[2];
                 }
+            };
+            auto wide_eval = [&](int iy0, const FeatRec (&fr)[WCH]) {
 #pragma unroll
                 for (int q = 0; q < WCH; q++) {
                     // straight-line code: the validity test is a mask, rows beyond the window land in a spare slot
@@ -621,6 +629,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PRE_WAVES, P
                     const int m = (int)__umul24((uint32_t)(wx + iabs(iy - R)), (uint32_t)feat_dist_w(fr[q].a, fr[q].b, fr[q].c, sp));
                     const int bad = (xok && ry >= 0 && ry < H) ? 0 : -1;
                     wide_m[iy < n ? ix * n + iy : ME_WIDE_LDS - 1] = m | bad;
+                }
+            };
+            {
+                constexpr int STEP = RPB * WCH;
+                FeatRec fa[WCH], fb[WCH];
+                wide_load(0, fa);
+                for (int iy0 = 0; iy0 < n; iy0 += 2 * STEP) {
+                    if (iy0 + STEP < n) wide_load(iy0 + STEP, fb);
+                    wide_eval(iy0, fa);
+                    if (iy0 + STEP < n) {
+                        if (iy0 + 2 * STEP < n) wide_load(iy0 + 2 * STEP, fa);
+                        wide_eval(iy0 + STEP, fb);
+                    }
                 }
             }
             {  // column n - 1
