@@ -839,39 +839,42 @@ __device__ __forceinline__ int walk_buckets_q(const FerDev &d, int s, const int 
             bs = (unsigned)__builtin_amdgcn_readlane((int)dstart, bb);
             bi = (uint32_t)__builtin_amdgcn_readlane((int)dinfo, bb);
         };
-        unsigned sA, sB;
-        uint32_t iA, iB;
-        uint32_t A0, A1, A2, B0, B1, B2;
+        // four batches in flight (the walk draws 70 % of the HBM bandwidth a copy reaches: two in flight left the wavefront
+        // waiting for every other batch), no register copies between them
+        unsigned sA, sB, sC, sD;
+        uint32_t iA, iB, iC, iD;
+        uint32_t A0, A1, A2, B0, B1, B2, C0, C1, C2, D0, D1, D2;
         desc(0, sA, iA);
         fetch(sA, (int)(iA & 127u), A0, A1, A2);
         desc(1, sB, iB);
         fetch(sB, (int)(iB & 127u), B0, B1, B2);
-        for (int b = 0; b < nb; b += 2) {  // two batches in flight, no register copies between them
-            if (filter(iA, A0, A1, A2)) {  // the sink has what it wanted
-                jend = (int)((iA >> 8) & 255u);
-                return true;
-            }
-            if (iA & 128u) {
-                if (tren > 128) {
-                    jend = (int)((iA >> 8) & 255u);
-                    return true;
-                }
-            }
-            desc(b + 2, sA, iA);
-            fetch(sA, (int)(iA & 127u), A0, A1, A2);
-            if (filter(iB, B0, B1, B2)) {  // (an empty batch when b + 1 == nb)
-                jend = (int)((iB >> 8) & 255u);
-                return true;
-            }
-            if (iB & 128u) {
-                if (tren > 128) {
-                    jend = (int)((iB >> 8) & 255u);
-                    return true;
-                }
-            }
-            desc(b + 3, sB, iB);
-            fetch(sB, (int)(iB & 127u), B0, B1, B2);
+        desc(2, sC, iC);
+        fetch(sC, (int)(iC & 127u), C0, C1, C2);
+        desc(3, sD, iD);
+        fetch(sD, (int)(iD & 127u), D0, D1, D2);
+#define WALK_STEP(SS, II, R0, R1, R2, NEXT)                                  \
+        if (filter(II, R0, R1, R2)) { /* the sink has what it wanted */      \
+            jend = (int)((II >> 8) & 255u);                                  \
+            return true;                                                     \
+        }                                                                    \
+        if (II & 128u) {                                                     \
+            if (tren > 128) {                                                \
+                jend = (int)((II >> 8) & 255u);                              \
+                return true;                                                 \
+            }                                                                \
+        }                                                                    \
+        desc(NEXT, SS, II);                                                  \
+        fetch(SS, (int)(II & 127u), R0, R1, R2);
+        for (int b = 0; b < nb; b += 4) {
+            WALK_STEP(sA, iA, A0, A1, A2, b + 4)
+            if (b + 1 >= nb) break;
+            WALK_STEP(sB, iB, B0, B1, B2, b + 5)
+            if (b + 2 >= nb) break;
+            WALK_STEP(sC, iC, C0, C1, C2, b + 6)
+            if (b + 3 >= nb) break;
+            WALK_STEP(sD, iD, D0, D1, D2, b + 7)
         }
+#undef WALK_STEP
         return false;
     };
     for (int j0 = 0; j0 <= 180; j0 += 16) {
