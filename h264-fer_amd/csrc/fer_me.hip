@@ -519,7 +519,7 @@ __device__ __forceinline__ int sad_lane(const IPlanes &ip, int W, int H, int sx,
 #define ME_WIDE_LDS 1156  // (2*16+2)^2: WindowSize <= 32 takes the LDS route (4.6 KB per wave)
 #define ME_SEL_NB 25      // 64-candidate batches of stage 3 at WindowSize 32: 18 wide + 7 local
 #ifndef PRE_WAVES
-#define PRE_WAVES 7  // wavefronts per SIMD the kernel is compiled for (register budget)
+#define PRE_WAVES 6  // wavefronts per SIMD the kernel is compiled for (register budget; its LDS allows 6.25)
 #endif
 template <int WIN>  // WindowSize known at compile time (0 = read it from d): divisions by the window become shifts/muls
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PRE_WAVES, PRE_WAVES))) void k_me_pre(FerDev d)
@@ -591,8 +591,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PRE_WAVES, P
     const uint16_t *F0 = d.feat0 + (size_t)s * 6 * ysz;
     const int wb = (n * n + 63) >> 6;  // batches of the wide search
     if ((WIN == 32 || WIN == 16) && !FER_DBGF(d, 3)) {
-        // the local search first (its row sums borrow the LDS of the wide search's metrics)
-        local_metrics<RRL>(ip, W, H, sx - r2, sy - r2, sp, lane, (uint32_t *)wide_m, sel_lds, 0, 2, &ld);
         // pass A: lanes run along x (contiguous 12-byte records); metrics land in LDS at their
         // arrival index (tx outer, ty inner).  Records are fetched six batches at a time with
         // clamped coordinates (no control flow around the loads), then masked.
@@ -634,7 +632,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PRE_WAVES, P
             {
                 constexpr int STEP = RPB * WCH;
                 FeatRec fa[WCH], fb[WCH];
-                wide_load(0, fa);
+                wide_load(0, fa);  // in flight during the local search
+                // the local search first (its row sums borrow the LDS of the wide search's metrics)
+                local_metrics<RRL>(ip, W, H, sx - r2, sy - r2, sp, lane, (uint32_t *)wide_m, sel_lds, 0, 2, &ld);
                 for (int iy0 = 0; iy0 < n; iy0 += 2 * STEP) {
                     if (iy0 + STEP < n) wide_load(iy0 + STEP, fb);
                     wide_eval(iy0, fa);
