@@ -104,15 +104,15 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
     unsigned *A = (unsigned *)sel, *B = A + 64;
     int *Ci = sel + 128, *Di = sel + 192;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int cntl = 0, lmin = 0x7fffffff, lmax = -1;
+    // (an invalid candidate is -1 = the largest unsigned value: unsigned minima and compares leave it out by themselves,
+    // and the valid ones are counted with one compare and a scalar population count per batch)
+    int lmin = 0x7fffffff, lmax = -1, total = 0;
 #pragma unroll
     for (int u = 0; u < NB; u++) {
-        bool ok = v[u] >= 0;
-        cntl += ok;
-        if (ok) lmin = min(lmin, v[u]);
+        total += __popcll(__ballot(v[u] >= 0));
+        lmin = (int)min((unsigned)lmin, (unsigned)v[u]);
         lmax = max(lmax, v[u]);
     }
-    const int total = wave_sum(cntl);
     const int need = min(K, total);
     L.m = INF_M;
     L.xy = 0;
@@ -148,7 +148,7 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
         if (T0 < (1 << 21) && NB * 64 <= 2048) {
 #pragma unroll
             for (int u = 0; u < NB; u++) {
-                const bool take = v[u] >= 0 && v[u] <= T0;
+                const bool take = (unsigned)v[u] <= (unsigned)T0;  // (T0 < 2^21: an invalid candidate never passes)
                 if (__any(take)) {
                     if (take) {
                         const int slot = atomicAdd(&Di[63], 1);
