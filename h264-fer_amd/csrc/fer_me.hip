@@ -18,7 +18,7 @@
 //                 centred ring scan for overflowed partitions) -- run for the guess and leave their lists with SADs;
 //   k_me_resolve  neighbour-dependent: the true predictor, P_Skip, and either the pricing of the guessed lists (the
 //                 guess was right: a few dozen instructions) or the chain's own search (it was wrong).  Persistent
-//                 workgroups of two wavefronts take (stream group, partition row) tickets from one queue per XCD,
+//                 single-wavefront workgroups take (stream group, partition row) tickets from one queue per XCD,
 //                 stealing from the other queues when theirs is empty, and chain along the row and to the row above
 //                 through self-validating 64-bit words (chain64): no launch per anti-diagonal, no grid-wide barrier.
 //                 (Partition merge, mvd, final motion compensation and source snapping follow in k_p_resid.)
@@ -1243,18 +1243,16 @@ __device__ __forceinline__ void take_best(int best, int bestxy, int &bmin, int &
 //
 // The searches that depend on the predictor were run beforehand for a GUESSED predictor (k_me_spec): the common step
 // of the chain is "compute the true predictor, find that its integer part is the guessed one, price the stored
-// candidate lists" -- a few dozen dependent instructions, evaluated by both wavefronts of the workgroup alike.
-// After a wrong guess the chain searches itself.  A wavefront that waits on its predecessor runs alone on its SIMD, so
-// every dependent instruction costs its full latency; the two searches are therefore split over the two wavefronts of
-// the workgroup: wavefront 0 runs stage 1 (top 17 around the predictor, their SADs) and merges; wavefront 1 re-ranks
-// the precomputed stage-2 set (top 33, their SADs) and the stage-3 survivors; they meet through LDS.
+// candidate lists" -- a few hundred instructions.  After a wrong guess the chain searches itself (stage 1, then stages
+// 2 and 3, in the same wavefront).  One wavefront per row: with thousands of rows in flight the launch is bound by the
+// instructions it issues, not by the latency of a row.
 // Everything after the vector of the partition is known (merge, mvd, final prediction, snapping, and the
 // reconstruction of P_Skip macroblocks) is not on any other partition's dependency chain and lives in k_p_resid
 // (fer_resid.hip).
 #define ST1_UNROLL 7
 #define RES_SPIN_LIMIT (1 << 23)
 
-struct ResPre {  // predictor-independent operands of one partition (role 1 needs all, role 0 the last two lines)
+struct ResPre {  // predictor-independent operands of one partition (res_prefetch: role 1 = all of them, role 0 = the last two lines)
     int n2, n3, n2raw;
     int2 e2[FER_ST2_CAP / 64];  // a crowded partition: e2[0] = (J, Dmin), e2[1].x = distance-0 candidates listed
     int2 z;                     // ... and the lane's distance-0 candidate
