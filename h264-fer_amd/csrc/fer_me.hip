@@ -98,8 +98,12 @@ __device__ __forceinline__ int lds_rank64(const unsigned *p, unsigned mine, int 
     return r;
 }
 
-template <int NB, class RAW, class FIN>
-__device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane, int *sel, WList &L, RAW raw, FIN fin)
+// ORDERED = the registers hold the candidates in arrival order (candidate (u, lane) arrived as number u * 64 + lane).  A caller whose
+// candidates sit in any order passes ORDERED = false and arr(u) = the lane's arrival number of candidate u (unique, < 2048): the
+// wide steps only need the number inside the sort key; the binary-search route relies on the register order and is not taken then
+// -- the function returns false and leaves the selection to the caller.
+template <int NB, bool ORDERED, class RAW, class FIN, class ARR>
+__device__ __forceinline__ bool select_topk_ex(const int (&v)[NB], int K, int lane, int *sel, WList &L, RAW raw, FIN fin, ARR arr)
 {
     unsigned *A = (unsigned *)sel, *B = A + 64;
     int *Ci = sel + 128, *Di = sel + 192;
@@ -116,11 +120,10 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
     const int need = min(K, total);
     L.m = INF_M;
     L.xy = 0;
-    if (need == 0) return;
+    if (need == 0) return true;
     int c = 65;
     if (!__any(lmax >= (1 << 26))) {
         B[lane] = 0xffffffffu;
-        if (lane == 0) Di[63] = 0;  // slot counter of the compaction below (Di[0 .. need-1] are written much later)
         // T0 = the need-th smallest per-lane minimum -- an upper bound of the need-th smallest candidate -- by binary search
         // over the value: one compare and one scalar population count per step.  (A rank computation over the 64 minima
         // through LDS cost 130 vector instructions here; these kernels are bound by vector issue, the scalar unit has room.)
@@ -146,21 +149,23 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
         // exact as long as the survivors' metrics stay below 2^21 (they are the smallest ones; larger takes the
         // general route).
         if (T0 < (1 << 21) && NB * 64 <= 2048) {
+            int nsurv = 0;  // (slots from a running scalar count and the lane's rank among the takers of its batch: an LDS
+                            // counter costs a wave-aggregated atomic, twenty instructions, per batch with a survivor)
 #pragma unroll
             for (int u = 0; u < NB; u++) {
                 const bool take = (unsigned)v[u] <= (unsigned)T0;  // (T0 < 2^21: an invalid candidate never passes)
-                if (__any(take)) {
-                    if (take) {
-                        const int slot = atomicAdd(&Di[63], 1);
-                        if (slot < 64) {
-                            B[slot] = ((unsigned)v[u] << 11) | (unsigned)(u * 64 + lane);
-                            Ci[slot] = raw(u);
-                        }
+                const unsigned long long mk = __ballot(take);
+                if (mk) {
+                    const int slot = nsurv + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                    if (take && slot < 64) {
+                        B[slot] = ((unsigned)v[u] << 11) | (unsigned)arr(u);
+                        Ci[slot] = raw(u);
                     }
+                    nsurv += __popcll(mk);
                 }
             }
             WAVE_LDS_SYNC();
-            c = Di[63];
+            c = nsurv;
         }
     }
     if (c <= 64) {
@@ -179,8 +184,9 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
             L.xy = fin(Di[lane]);
         }
         WAVE_LDS_SYNC();
-        return;
+        return true;
     }
+    if (!ORDERED) return false;
     // ---- general route: binary-search the need-th smallest metric with ballot counts, take everything
     // below it plus the earliest arrivals equal to it, then rank the winners
     int *key = sel, *kxy = sel + 64, *key2 = sel + 128, *kxy2 = sel + 192;
@@ -238,6 +244,12 @@ __device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane,
         L.xy = fin(kxy2[lane]);
     }
     WAVE_LDS_SYNC();
+    return true;
+}
+template <int NB, class RAW, class FIN>
+__device__ __forceinline__ void select_topk(const int (&v)[NB], int K, int lane, int *sel, WList &L, RAW raw, FIN fin)
+{
+    select_topk_ex<NB, true>(v, K, lane, sel, L, raw, fin, [&](int u) { return u * 64 + lane; });
 }
 
 // ---- the 9-term feature distance of F/moestimation.cpp:267-276 on packed 16-bit pairs ----
@@ -519,7 +531,7 @@ __device__ __forceinline__ int sad_lane(const IPlanes &ip, int W, int H, int sx,
 #define ME_WIDE_LDS 1156  // (2*16+2)^2: WindowSize <= 32 takes the LDS route (4.6 KB per wave)
 #define ME_SEL_NB 25      // 64-candidate batches of stage 3 at WindowSize 32: 18 wide + 7 local
 #ifndef PRE_WAVES
-#define PRE_WAVES 6  // wavefronts per SIMD the kernel is compiled for (register budget; its LDS allows 6.25)
+#define PRE_WAVES 5  // wavefronts per SIMD the kernel is compiled for (register budget; flat from 5 up, its LDS allows 6.25)
 #endif
 template <int WIN>  // WindowSize known at compile time (0 = read it from d): divisions by the window become shifts/muls
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PRE_WAVES, PRE_WAVES))) void k_me_pre(FerDev d)
@@ -591,22 +603,130 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PRE_WAVES, P
     const uint16_t *F0 = d.feat0 + (size_t)s * 6 * ysz;
     const int wb = (n * n + 63) >> 6;  // batches of the wide search
     if ((WIN == 32 || WIN == 16) && !FER_DBGF(d, 3)) {
-        // pass A: lanes run along x (contiguous 12-byte records); metrics land in LDS at their
-        // arrival index (tx outer, ty inner).  Records are fetched six batches at a time with
-        // clamped coordinates (no control flow around the loads), then masked.
+        // n = WIN + 1: a batch of the wide search is 64 / WIN rows of the first WIN columns, so the column, its validity and its
+        // weight are per-lane constants and a row step is one address increment; the last column follows
         constexpr int WCH = 6;
-        if (WIN == 32 || WIN == 16) {
-            // n = WIN + 1: a batch is 64 / WIN rows of the first WIN columns, so the column, its validity and its
-            // weight are per-lane constants and a row step is one address increment; the last column follows
-            constexpr int NBc = WIN ? WIN : 32, RPB = 64 / NBc;
-            const int ix = lane % NBc, r0 = lane / NBc;
-            const int rx = sx - R + ix;
-            const bool xok = rx >= 0 && rx < W;
-            const int wx = iabs(ix - R) + 4;
-            // (32-bit byte offsets from the stream's uniform base: a record load is one instruction with a scalar base,
-            // where 64-bit index arithmetic costs nine VALU instructions per load)
-            const uint32_t colo = (uint32_t)iclamp(rx, 0, W - 1) * 12u, rowb = (uint32_t)W * 12u;
-            // the records of the next six batches are in flight while the current six are evaluated
+        constexpr int NN = (WIN ? WIN : 32) + 1;
+        constexpr int NBc = WIN ? WIN : 32, RPB = 64 / NBc, NWB = (NN + RPB - 1) / RPB;
+        constexpr int LB = LocalGeo<RRL>::NB;  // batches of the local search
+        static_assert(LB <= 7, "ME_SEL_NB leaves room for 7 local batches");
+        const int ix = lane % NBc, r0 = lane / NBc;
+        const int rx = sx - R + ix;
+        const bool xok = rx >= 0 && rx < W;
+        const int wx = iabs(ix - R) + 4;
+        // (32-bit byte offsets from the stream's uniform base: a record load is one instruction with a scalar base,
+        // where 64-bit index arithmetic costs nine VALU instructions per load)
+        const uint32_t colo = (uint32_t)iclamp(rx, 0, W - 1) * 12u, rowb = (uint32_t)W * 12u;
+        auto fin = [&](int idx) {  // arrival index -> the candidate's vector
+            if (idx < wb * 64) return pack_xy((idx / n - R) * 4, (idx % n - R) * 4);
+            int c = idx - wb * 64;
+            int frac = c & 15, pos = c >> 4;
+            return pack_xy((pos / n2w - r2) * 4 + (frac & 3), (pos % n2w - r2) * 4 + (frac >> 2));
+        };
+        // ---- Pruning by a lower bound.  metric = w * D with D = |s0 - k0| + sum over the four half sums of
+        // (|si - ki| + |(s0 - si) - (k0 - ki)|) >= 5 |s0 - k0| (each pair is at least |s0 - k0| by the triangle inequality),
+        // so w * 5 |s0 - k0| bounds a candidate from below with the FIRST dword of its record.  With T = an upper bound of
+        // the 33rd smallest metric (the 33rd smallest per-lane minimum of the local search, which runs first), a wide
+        // candidate whose bound exceeds T cannot enter the list (33 candidates are strictly better); the others -- a few
+        // dozen of the 1089 -- are evaluated in full.  More than 128 survivors (flat content: every bound is 0) or a
+        // selection that cannot take its wide route fall back to the full evaluation below.
+        uint32_t k0w[NWB];
+#pragma unroll
+        for (int b2 = 0; b2 < NWB; b2++) {  // in flight during the local search
+            const int ry = iclamp(sy - R + b2 * RPB + r0, 0, H - 1);
+            k0w[b2] = *(const uint32_t *)((const char *)F0 + (colo + __umul24((uint32_t)ry, rowb)));
+        }
+        const uint32_t k0c = feat0_load(F0, W, H, sy - R + min(lane, NN - 1), sx + R).a;  // column n - 1
+        // the local search first (its row sums borrow the LDS of the wide search's metrics)
+        local_metrics<RRL>(ip, W, H, sx - r2, sy - r2, sp, lane, (uint32_t *)wide_m, sel_lds, 0, 2, &ld);
+        int vloc[LB];
+        unsigned lminl = 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < LB; u++) {
+            vloc[u] = sel_lds[u * 64 + lane];
+            lminl = min(lminl, (unsigned)vloc[u]);
+        }
+        int T = 0x7fffffff;
+        if (__popcll(__ballot(lminl < (1u << 21))) >= 33) {
+            int lo = 0, hi = (1 << 21) - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (__popcll(__ballot(lminl <= (unsigned)mid)) >= 33)
+                    hi = mid;
+                else
+                    lo = mid + 1;
+            }
+            T = lo;
+        }
+        int *surv = wide_m;  // arrival numbers of the surviving wide candidates; the row sums are dead
+        int ns = 0;
+        const uint32_t s0 = (uint32_t)su[0];
+        bool done = false;
+        if (T != 0x7fffffff) {
+#pragma unroll
+            for (int b2 = 0; b2 < NWB; b2++) {
+                const int iy = b2 * RPB + r0;
+                const int ry = sy - R + iy;
+                const uint32_t lb = __umul24(5u * (uint32_t)(wx + iabs(iy - R)), __builtin_amdgcn_sad_u16(k0w[b2] & 0xffffu, s0, 0u));
+                const bool take = xok && ry >= 0 && ry < H && iy < NN && lb <= (uint32_t)T;
+                const unsigned long long mk = __ballot(take);
+                if (mk) {
+                    const int slot = ns + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                    if (take && slot < 128) surv[slot] = ix * NN + iy;
+                    ns += __popcll(mk);
+                }
+            }
+            {  // column n - 1
+                const int iy = lane, ry = sy - R + iy;
+                const uint32_t lb = __umul24(5u * (uint32_t)(R + 4 + iabs(iy - R)), __builtin_amdgcn_sad_u16(k0c & 0xffffu, s0, 0u));
+                const bool take = iy < NN && sx + R < W && ry >= 0 && ry < H && lb <= (uint32_t)T;
+                const unsigned long long mk = __ballot(take);
+                if (mk) {
+                    const int slot = ns + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                    if (take && slot < 128) surv[slot] = (NN - 1) * NN + iy;
+                    ns += __popcll(mk);
+                }
+            }
+            WAVE_LDS_SYNC();
+            if (ns <= 128) {
+                int v[2 + LB], ar[2];
+#pragma unroll
+                for (int b2 = 0; b2 < 2; b2++) {
+                    v[b2] = -1;
+                    ar[b2] = 0;
+                    if (b2 * 64 < ns) {  // (the second batch is rarely needed)
+                        const int idx = b2 * 64 + lane;
+                        const bool on = idx < ns;
+                        const int ai = on ? surv[idx] : 0;
+                        const int cix = ai / NN, ciy = ai - cix * NN;
+                        const FeatRec f = feat0_load(F0, W, H, sy - R + ciy, sx - R + cix);
+                        const int m = (int)__umul24((uint32_t)(iabs(cix - R) + iabs(ciy - R) + 4), (uint32_t)feat_dist_w(f.a, f.b, f.c, sp));
+                        v[b2] = on ? m : -1;
+                        ar[b2] = ai;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < LB; u++) v[2 + u] = vloc[u];
+                WAVE_LDS_SYNC();  // the selection reuses sel_lds
+                auto arrv = [&](int u) { return u < 2 ? ar[u < 2 ? u : 0] : wb * 64 + (u - 2) * 64 + lane; };
+                done = select_topk_ex<2 + LB, false>(v, 33, lane, sel_lds, L, arrv, fin, arrv);
+            }
+        }
+        PP_MARK(1)
+#ifdef FER_STATS
+        if (lane == 0) {
+            atomicAdd((unsigned long long *)&d.timing[48], 1ull);
+            atomicAdd((unsigned long long *)&d.timing[49], done ? 0ull : 1ull);
+            atomicAdd((unsigned long long *)&d.timing[50], (unsigned long long)ns);
+            atomicAdd((unsigned long long *)&d.timing[51], T == 0x7fffffff ? 1ull : 0ull);
+            atomicAdd((unsigned long long *)&d.timing[52], (unsigned long long)(T == 0x7fffffff ? 0 : T));
+        }
+#endif
+        if (!done) {
+            // ---- the full evaluation: lanes run along x (contiguous 12-byte records); metrics land in LDS at their
+            // arrival index (tx outer, ty inner).  Records are fetched six batches at a time with clamped coordinates
+            // (no control flow around the loads), then masked; the next six are in flight while six are evaluated.
+            WAVE_LDS_SYNC();
             auto wide_load = [&](int iy0, FeatRec (&fr)[WCH]) {
 #pragma unroll
                 for (int q = 0; q < WCH; q++) {
@@ -632,9 +752,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PRE_WAVES, P
             {
                 constexpr int STEP = RPB * WCH;
                 FeatRec fa[WCH], fb[WCH];
-                wide_load(0, fa);  // in flight during the local search
-                // the local search first (its row sums borrow the LDS of the wide search's metrics)
-                local_metrics<RRL>(ip, W, H, sx - r2, sy - r2, sp, lane, (uint32_t *)wide_m, sel_lds, 0, 2, &ld);
+                wide_load(0, fa);
                 for (int iy0 = 0; iy0 < n; iy0 += 2 * STEP) {
                     if (iy0 + STEP < n) wide_load(iy0 + STEP, fb);
                     wide_eval(iy0, fa);
@@ -652,51 +770,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PRE_WAVES, P
                 if (!(rxl < W && ry >= 0 && ry < H)) m = -1;
                 if (lane < n) wide_m[(n - 1) * n + iy] = m;
             }
-        } else
-        for (int base = 0; base < n * n; base += 64 * WCH) {
-            FeatRec fr[WCH];
+            __syncthreads();
+            int v[ME_SEL_NB];
 #pragma unroll
-            for (int q = 0; q < WCH; q++) {
-                int c = min(base + q * 64 + lane, n * n - 1);
-                fr[q] = feat0_load(F0, W, H, sy + c / n - R, sx + c % n - R);
+            for (int u = 0; u < ME_SEL_NB; u++) {
+                v[u] = -1;
+                if (u < wb) {
+                    int c = u * 64 + lane;
+                    if (c < n * n) v[u] = wide_m[c];
+                } else if (u - wb < LB) {
+                    v[u] = vloc[u - wb < LB ? u - wb : 0];
+                }
             }
-#pragma unroll
-            for (int q = 0; q < WCH; q++) {
-                int c = base + q * 64 + lane;
-                int cc = min(c, n * n - 1);
-                int iy = cc / n, ix = cc % n;
-                int tx = ix - R, ty = iy - R;
-                int rx = sx + tx, ry = sy + ty;
-                int m = (iabs(tx) + iabs(ty) + 4) * feat_dist_w(fr[q].a, fr[q].b, fr[q].c, sp);
-                if (!(rx >= 0 && rx < W && ry >= 0 && ry < H)) m = -1;
-                if (c < n * n) wide_m[ix * n + iy] = m;
-            }
+            WAVE_LDS_SYNC();  // the selection reuses sel_lds
+            auto raw = [&](int u) { return u * 64 + lane; };  // arrival index
+            PP_MARK(2)
+            select_topk<ME_SEL_NB>(v, 33, lane, sel_lds, L, raw, fin);
         }
-        __syncthreads();
-        PP_MARK(1)
-        constexpr int LB = LocalGeo<(WIN ? WIN : 32) / 16>::NB;  // batches of the local search
-        static_assert(LB <= 7, "ME_SEL_NB leaves room for 7 local batches");
-        int v[ME_SEL_NB];
-#pragma unroll
-        for (int u = 0; u < ME_SEL_NB; u++) {
-            v[u] = -1;
-            if (u < wb) {
-                int c = u * 64 + lane;
-                if (c < n * n) v[u] = wide_m[c];
-            } else if (u - wb < LB) {
-                v[u] = sel_lds[(u - wb < LB ? u - wb : 0) * 64 + lane];
-            }
-        }
-        WAVE_LDS_SYNC();  // the selection reuses sel_lds
-        auto raw = [&](int u) { return u * 64 + lane; };  // arrival index
-        auto fin = [&](int idx) {                          // ... to the candidate's vector
-            if (idx < wb * 64) return pack_xy((idx / n - R) * 4, (idx % n - R) * 4);
-            int c = idx - wb * 64;
-            int frac = c & 15, pos = c >> 4;
-            return pack_xy((pos / n2w - r2) * 4 + (frac & 3), (pos % n2w - r2) * 4 + (frac >> 2));
-        };
-        PP_MARK(2)
-        select_topk<ME_SEL_NB>(v, 33, lane, sel_lds, L, raw, fin);
         PP_MARK(3)
     } else {
         for (int base = 0; base < n * n && !FER_DBGF(d, 1); base += 64) {
