@@ -15,7 +15,8 @@ for it in range(N):
     W, H = rng.choice([(176, 144), (352, 288), (64, 48), (128, 96), (320, 240), (16, 32), (48, 16)])
     cfg = dict(qp=rng.choice([10, 12, 16, 20, 24, 28, 30]), window=rng.choice([16, 32, 32, 32, 48]),
                maxdiff=rng.choice([3, 3, -1, 0, 6]), intra_every=rng.choice([30, 30, 3, 2]))
-    T, S = rng.choice([3, 4, 5]), rng.choice([1, 2, 3])
+    T, S = rng.choice([3, 4, 5]), rng.choice([1, 2, 3, 3, 17, 19])   # >= 16 streams: the eight ticket queues of the motion chain
+    tune = (rng.choice([1, 2, 5, 8, 64, 6144]), rng.choice([1, 2, 4, 64]), rng.choice([0, 1, 1, 1]))
     noise = rng.choice([0, 1, 2, 4])
     seeds = [rng.randrange(1, 10000) for _ in range(S)]
     still = rng.random() < 0.25  # static content: P_Skip heavy
@@ -34,6 +35,9 @@ for it in range(N):
                 else:
                     y[: 8 * rng.randrange(2, 5)] = 0
     g = pkg.FerHip(W, H, S, **cfg)
+    g.tune(pkg.TUNE_RESOLVE_WGS, tune[0])
+    g.tune(pkg.TUNE_RESOLVE_GROUP, tune[1])
+    g.tune(pkg.TUNE_SPECULATE, tune[2])
     streams, rec = g.encode_streams(frames, want_recon=True)
     st = g.status()
     g.close()
@@ -67,5 +71,5 @@ for it in range(N):
     ok &= not why
     if not ok:
         bad += 1
-    print(("ok  " if ok else "FAIL"), W, H, T, S, cfg, "noise", noise, "still", still, shape, "status", st, " ".join(why), flush=True)
+    print(("ok  " if ok else "FAIL"), W, H, T, S, cfg, "noise", noise, "still", still, shape, "tune", tune, "status", st, " ".join(why), flush=True)
 print("failures:", bad, "of", N)
