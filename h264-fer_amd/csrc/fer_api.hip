@@ -287,12 +287,11 @@ static int ctx_create(ferhip_ctx **out, int W, int H, int S, const ferhip_params
     rc |= dalloc(c, &d.dec_cac, (size_t)128 * S);
     int n = W * H;
     c->sort.tmp_bytes = fer_sort_tmp_bytes(n, S);
-    rc |= dalloc(c, &c->sort.recT, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
+    rc |= dalloc(c, &c->sort.rec_tmp, decode_only ? (size_t)1 : (size_t)((size_t)n * S * 3));
     rc |= dalloc(c, &c->sort.rec1, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
     rc |= dalloc(c, &c->sort.keyT, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
     rc |= dalloc(c, &c->sort.dig2, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
     rc |= dalloc(c, &c->sort.skey, decode_only ? (size_t)1 : (size_t)((size_t)n * S));
-    c->sort.rec_tmp = (uint32_t *)c->sort.recT;  // the arrival-order records are dead once the first pass has read them
     uint8_t *tmp = nullptr;
     rc |= dalloc(c, &tmp, decode_only ? (size_t)1 : (size_t)(c->sort.tmp_bytes));
     c->sort.tmp = tmp;

@@ -3,12 +3,11 @@
 #include "fer_dev.h"
 
 struct FerSortTmp {
-    uint4 *recT;        // [S][W][H] plane-0 records + position in arrival order (k_feat0)
-    uint4 *rec1;        // [S][n] the same after the first radix pass
+    uint4 *rec1;        // [S][n] plane-0 records + position (k0|k1, k2|k3, k4, tx<<16|ty) after the first radix pass
     uint16_t *keyT;     // [S][W][H] sort keys in arrival order
     uint8_t *dig2;      // [S][n] high digit of the keys after the first pass
     uint16_t *skey;     // [S][n] sorted keys
-    uint32_t *rec_tmp;  // [S][n][3] plain sorted records of streams that take the reference's mis-filed layout (aliases recT)
+    uint32_t *rec_tmp;  // [S][n][3] plain sorted records of streams that take the reference's mis-filed layout 
     void *tmp;          // digit histograms
     size_t tmp_bytes;
 };

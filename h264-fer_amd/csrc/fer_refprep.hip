@@ -207,18 +207,19 @@ __global__ __launch_bounds__(256) void k_features(FerDev d)
 // ------------------------------------------------------------------ k_feat0
 // Plane 0 of the feature table straight from the reference luma (interpolated plane 0 IS the reference picture):
 //   feat0 [H][W]   12-byte records (k0|k1, k2|k3, k4) row-major, what the wide integer search streams;
-//   recT  [W][H]   16-byte records (k0|k1, k2|k3, k4, tx<<16|ty) in ARRIVAL order b = tx*H + ty of the reference's
-//                  counting sort (F/moestimation.cpp:142-151 scans columns) -- the input of the radix passes;
-//   keyT  [W][H]   the sort key k0 alone (uint16), so that the histogram passes read 2 bytes per position.
+//   keyT  [W][H]   the sort key k0 alone (uint16) in ARRIVAL order b = tx*H + ty of the reference's counting sort
+//                  (F/moestimation.cpp:142-151 scans columns): what the histogram of the first radix pass reads.
+// The records of the sort itself are not written here: the first scatter pass rebuilds them from the samples of its
+// own tile (k_rs_scatter<0>), which is cheaper than a 16-byte record per position written and read back once.
 // One workgroup per 64x64 tile of positions: the (64+7)^2 samples (replicated beyond the picture, like the
 // reference's 8-pixel padding :107-115) go to LDS once; a thread owns a column of 16 positions, takes the horizontal
 // partial sums of each input row with v_sad_u8 and keeps the last 8 rows in registers (the scheme of k_features);
-// finished records are transposed through LDS so that both outputs are written in long contiguous runs.
+// the keys are transposed through LDS so that both outputs are written in long contiguous runs.
 #define F0_T 64
-__global__ __launch_bounds__(256) void k_feat0(FerDev d, uint4 *recT, uint16_t *keyT)
+__global__ __launch_bounds__(256) void k_feat0(FerDev d, uint16_t *keyT)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[F0_T + 7][F0_T + 8];
-    __shared__ __attribute__((aligned(16))) uint32_t stage[F0_T][F0_T + 1][3];  // [x][y]: + 1 breaks the bank stride
+    __shared__ uint16_t stage[F0_T][F0_T + 2];  // [x][y]: + 2 breaks the bank stride
     const int s = blockIdx.z;
     if (d.hdr[s * 4 + 3] != 0) return;
     const int W = d.W, H = d.H;
@@ -265,9 +266,7 @@ __global__ __launch_bounds__(256) void k_feat0(FerDev d, uint4 *recT, uint16_t *
             const int k1 = h8[(j + 1) & 7] + h8[(j + 2) & 7] + h8[(j + 3) & 7] + h8[(j + 4) & 7];
             const int k3 = h8[(j + 1) & 7] + h8[(j + 2) & 7] + h8[(j + 5) & 7] + h8[(j + 6) & 7];
             const uint32_t a = (uint32_t)k0 | ((uint32_t)k1 << 16), b = (uint32_t)k2 | ((uint32_t)k3 << 16), c = (uint32_t)k4;
-            stage[x][yo][0] = a;
-            stage[x][yo][1] = b;
-            stage[x][yo][2] = c;
+            stage[x][yo] = (uint16_t)k0;
             const int gx = x0 + x, gy = y0 + yo;
             if (gx < W && gy < H) {
                 uint32_t *o = (uint32_t *)(d.feat0 + ((size_t)s * d.ysz + (size_t)gy * W + gx) * 6);
@@ -283,16 +282,12 @@ __global__ __launch_bounds__(256) void k_feat0(FerDev d, uint4 *recT, uint16_t *
         if ((tid & 63) == 0 && tot) atomicAdd(&d.zero_cnt[s], tot);
     }
     __syncthreads();
-    // column-major outputs: thread = (column, 16 consecutive rows of it)
-    for (int i = tid; i < F0_T * F0_T; i += 256) {
-        const int cx = i >> 6, cy = i & 63;
+    // column-major keys: a pair of rows per thread, 32 threads = one column of the tile (H is even)
+    for (int i = tid; i < F0_T * F0_T / 2; i += 256) {
+        const int cx = i >> 5, cy = (i & 31) * 2;
         const int gx = x0 + cx, gy = y0 + cy;
-        if (gx < W && gy < H) {
-            const size_t bidx = (size_t)s * d.ysz + (size_t)gx * H + gy;
-            const uint32_t a = stage[cx][cy][0];
-            recT[bidx] = make_uint4(a, stage[cx][cy][1], stage[cx][cy][2], ((uint32_t)gx << 16) | (uint32_t)gy);
-            keyT[bidx] = (uint16_t)(a & 0xffffu);
-        }
+        if (gx < W && gy < H)
+            *(uint32_t *)(keyT + (size_t)s * d.ysz + (size_t)gx * H + gy) = (uint32_t)stage[cx][cy] | ((uint32_t)stage[cx][cy + 1] << 16);
     }
 }
 
@@ -379,14 +374,45 @@ __global__ __launch_bounds__(256) void k_rs_scan(FerDev d, uint32_t *hist, int n
 // 64 items per round: the rank of an item among the earlier items of its digit comes from ballot matching plus a
 // per-wavefront running count per digit.  The tile is then put in output order inside LDS (digit runs one after the
 // other) and written out, so that neighbouring threads write neighbouring addresses of the same digit run.
-// pass 0: in = recT (arrival order), out = rec1 (16 B) + dig2 (high digit);  pass 1: in = rec1, out = final arrays.
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint16_t *keyT, const uint8_t *dig2_in, const uint4 *rec_in,
-                                                          uint4 *rec1_out, uint8_t *dig2_out, uint32_t *rec_tmp, uint16_t *skey,
-                                                          const uint32_t *hist, int ntiles, int pass)
+// pass 0: in = the reference luma (records rebuilt per tile, below), out = rec1 (16 B) + dig2 (high digit);
+// pass 1: in = rec1, out = final arrays.
+//
+// Pass 0 builds its 4096 records (k0|k1, k2|k3, k4, tx<<16|ty -- the values k_feat0 writes row-major) itself.  The tile
+// is a run of arrival indices b = tx*H + ty, i.e. nc column segments (tx, rows [ys, ye)); rows (segment, r) for
+// r in [ys, ye + 7) are numbered q = 0 .. Q-1 one segment after the other (u = q + ya = c*(H+7) + r).
+//   1. the samples those rows need go to LDS -- one box of columns [xa, xb + 7] x all rows when the tile spans three
+//      or more columns, one 12-byte-wide box per segment otherwise (tall pictures) --, replicated beyond the picture;
+//   2. a thread takes a run of q's: horizontal sums (h8 | h4 << 16, hc in the high dword: one u64 per row), summed
+//      into an exclusive prefix PL over the whole q sequence (an exact integer, 55 bits at most: a difference of two
+//      entries of one segment is the three window sums side by side, 16 bits apart);
+//   3. an item reads PL at its window's rows 0, 2, 4, 6, 8.
+// Samples, PL and the output staging share the same 64 KB of LDS, one after the other.
+#define RS_SEG_PITCH 12
+__device__ __forceinline__ void rs_divmod(unsigned v, unsigned dv, float rdv, unsigned &qo, unsigned &rem)
+{  // v < 2^28, dv <= 2^15: the float quotient is off by one at most
+    int q = (int)((float)v * rdv);
+    int r = (int)v - q * (int)dv;
+    if (r < 0) {
+        q--;
+        r += (int)dv;
+    }
+    if (r >= (int)dv) {
+        q++;
+        r -= (int)dv;
+    }
+    qo = (unsigned)q;
+    rem = (unsigned)r;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint8_t *dig2_in, const uint4 *rec_in, uint4 *rec1_out,
+                                                          uint8_t *dig2_out, uint32_t *rec_tmp, uint16_t *skey, const uint32_t *hist,
+                                                          int ntiles)
 {
     __shared__ unsigned run[RS_THREADS / 64][RS_ND];  // per wavefront: items of each digit seen so far
     __shared__ unsigned base[RS_ND], dstart[RS_ND];
     __shared__ unsigned wsum[RS_THREADS / 64];
+    __shared__ unsigned long long wtot[RS_THREADS / 64];
     __shared__ __attribute__((aligned(16))) uint4 srec[RS_TILE];
     const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     if (d.hdr[s * 4 + 3] != 0) return;
@@ -398,15 +424,123 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint1
         for (int w = 0; w < RS_THREADS / 64; w++) run[w][tid] = 0;
         base[tid] = hist[((size_t)s * RS_ND + tid) * ntiles + tile];
     }
-    __syncthreads();
     const int w0 = tile * RS_TILE + wv * (RS_TILE / (RS_THREADS / 64));
     unsigned dg[RS_ITEMS], rk[RS_ITEMS];
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint4 rec[PASS == 0 ? RS_ITEMS : 1];
+    if (PASS == 0) {
+        const int W = d.W, H = d.H;
+        const uint8_t *R = d.refY + (size_t)s * d.ysz;
+        uint8_t *smp = (uint8_t *)srec;
+        unsigned long long *PL = (unsigned long long *)srec;
+        const int t0 = tile * RS_TILE, cnt = min(RS_TILE, n - t0);
+        const int xa = t0 / H, ya = t0 - xa * H, xb = (t0 + cnt - 1) / H;
+        const int nc = xb - xa + 1, Q = cnt + 7 * nc;
+        const int HR = H + 7;
+        const float rHR = 1.0f / (float)HR, rH = 1.0f / (float)H;
+        const bool shared_box = nc >= 3;
+        // sample (segment c, picture row r, first column of the segment) sits at smp[segb(c) + r * pitch]
+        const int pitch = shared_box ? (((xb + 7) >> 2) - (xa >> 2) + 1) * 4 : RS_SEG_PITCH;
+        const int rows0 = shared_box ? HR : (nc == 1 ? cnt + 7 : HR - ya);  // rows of the first box
+        // 1. samples
+        {
+            const int nd = pitch / 4;
+            const int nboxes = shared_box ? 1 : nc;
+            for (int bx = 0; bx < nboxes; bx++) {
+                const int nr = bx == 0 ? rows0 : (t0 + cnt - xb * H) + 7;  // the last segment starts at row 0
+                const int xs = (xa + bx) & ~3, r0 = (shared_box || bx) ? 0 : ya;
+                uint8_t *dst = smp + (bx ? rows0 * RS_SEG_PITCH : 0);
+                for (int i = tid; i < nr * nd; i += RS_THREADS) {
+                    unsigned r, c4;
+                    rs_divmod((unsigned)i, (unsigned)nd, 1.0f / (float)nd, r, c4);
+                    const int gx = xs + (int)c4 * 4, gy = min(r0 + (int)r, H - 1);
+                    const uint8_t *row = R + (size_t)gy * W;
+                    const uint32_t v = gx < W ? *(const uint32_t *)(row + gx) : (uint32_t)row[W - 1] * 0x01010101u;
+                    *(uint32_t *)(dst + (int)r * pitch + (int)c4 * 4) = v;
+                }
+            }
+        }
+        __syncthreads();
+        // 2. horizontal sums of a run of rows, prefix
+        const int L = (Q + RS_THREADS - 1) / RS_THREADS;  // <= 12 (H = 16: 257 segments)
+        const int q0 = min(tid * L, Q), q1 = min(q0 + L, Q);
+        unsigned long long hv[12];
+        unsigned long long tot = 0;
+        {
+            unsigned c, r;
+            rs_divmod((unsigned)(q0 + ya), (unsigned)HR, rHR, c, r);
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        const int idx = w0 + r * 64 + lane;
-        dg[r] = idx < n ? rs_digit(keyT, dig2_in, pass, g0 + idx) : 0u;
+            for (int k = 0; k < 12; k++) {
+                hv[k] = 0;
+                if (q0 + k < q1) {
+                    int a;
+                    if (shared_box)
+                        a = (int)r * pitch + (xa & 3) + (int)c;
+                    else
+                        a = (c ? rows0 * RS_SEG_PITCH + (int)r * RS_SEG_PITCH : ((int)r - ya) * RS_SEG_PITCH) + ((xa + (int)c) & 3);
+                    const uint32_t *w = (const uint32_t *)(smp + (a & ~3));
+                    const uint32_t sh = (uint32_t)(a & 3);
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], sh);
+                    const uint32_t hi = __builtin_amdgcn_alignbyte(w[2], w[1], sh);
+                    const uint32_t a4 = __builtin_amdgcn_sad_u8(lo, 0u, 0u);
+                    const uint32_t a8 = __builtin_amdgcn_sad_u8(hi, 0u, a4);
+                    const uint32_t ac = __builtin_amdgcn_sad_u8(hi & 0xffffu, 0u, __builtin_amdgcn_sad_u8(lo & 0xffffu, 0u, 0u));
+                    hv[k] = ((unsigned long long)ac << 32) | (a8 | (a4 << 16));
+                    tot += hv[k];
+                    if (++r == (unsigned)HR) {
+                        r = 0;
+                        c++;
+                    }
+                }
+            }
+        }
+        unsigned long long inc = tot;  // inclusive scan of the thread totals over the workgroup
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned lo = (unsigned)__shfl_up((int)(unsigned)inc, o), hi = (unsigned)__shfl_up((int)(unsigned)(inc >> 32), o);
+            if (lane >= o) inc += ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == 63) wtot[wv] = inc;
+        __syncthreads();  // (also: every thread has read its samples)
+        unsigned long long pre = inc - tot;
+        for (int w = 0; w < wv; w++) pre += wtot[w];
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+            if (q0 + k < q1) {
+                PL[q0 + k] = pre;
+                pre += hv[k];
+            }
+        if (q0 < Q && q1 == Q) PL[Q] = pre;
+        __syncthreads();
+        // 3. the items of this thread
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++) {
+            const int idx = w0 + r * 64 + lane;
+            dg[r] = 0;
+            rec[r] = make_uint4(0, 0, 0, 0);
+            if (idx < n) {
+                unsigned x, y;
+                rs_divmod((unsigned)idx, (unsigned)H, rH, x, y);
+                const int c = (int)x - xa;
+                const int q = c * HR + (int)y - ya;  // row y of segment c
+                const unsigned long long p0 = PL[q], p8 = PL[q + 8];
+                const uint32_t *pl = (const uint32_t *)PL;
+                const uint32_t l0 = (uint32_t)p0, l2 = pl[(q + 2) * 2], l4 = pl[(q + 4) * 2], l6 = pl[(q + 6) * 2];
+                const unsigned long long dd = p8 - p0;
+                const uint32_t k0 = (uint32_t)dd & 0xffffu, k2 = (uint32_t)(dd >> 16) & 0xffffu, k4 = (uint32_t)(dd >> 32) & 0xffffu;
+                const uint32_t k1 = (l4 - l0) & 0xffffu, k3 = ((l2 - l0) + (l6 - l4)) & 0xffffu;
+                rec[r] = make_uint4(k0 | (k1 << 16), k2 | (k3 << 16), k4, (x << 16) | y);
+                dg[r] = k0 & (RS_ND - 1);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++) {
+            const int idx = w0 + r * 64 + lane;
+            dg[r] = idx < n ? (unsigned)dig2_in[g0 + idx] : 0u;
+        }
     }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const bool ok = w0 + r * 64 + lane < n;
@@ -447,20 +581,20 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint1
         for (int w = 0; w < wv; w++) before += wsum[w];
         if (tid < RS_ND) dstart[tid] = before + inc - tot;
     }
-    __syncthreads();
+    __syncthreads();  // (pass 0: the prefix table in srec's place is dead)
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const int idx = w0 + r * 64 + lane;
-        if (idx < n) srec[dstart[dg[r]] + run[wv][dg[r]] + rk[r]] = rec_in[g0 + idx];
+        if (idx < n) srec[dstart[dg[r]] + run[wv][dg[r]] + rk[r]] = PASS == 0 ? rec[r] : rec_in[g0 + idx];
     }
     __syncthreads();
     const int cnt = min(RS_TILE, n - tile * RS_TILE);
-    if (pass == 0) {
+    if (PASS == 0) {
         for (int i = tid; i < cnt; i += RS_THREADS) {
             const uint4 v = srec[i];
             const unsigned key = v.x & 0xffffu;
             const unsigned dgi = key & (RS_ND - 1);
-            const size_t pos = g0 + base[dgi] + ((unsigned)i - dstart[dgi]);
+            const size_t pos = g0 + min(base[dgi] + ((unsigned)i - dstart[dgi]), (unsigned)n - 1u);  // (in range by construction)
             rec1_out[pos] = v;
             dig2_out[pos] = (uint8_t)(key >> RS_BITS);
         }
@@ -674,7 +808,7 @@ void fer_launch_sort_keys(const FerDev &d, FerSortTmp &t, hipStream_t st)
 {
     hipMemsetAsync(d.zero_cnt, 0, sizeof(int) * d.S, st);
     dim3 g((d.W + F0_T - 1) / F0_T, (d.H + F0_T - 1) / F0_T, d.S);
-    hipLaunchKernelGGL(k_feat0, g, dim3(256), 0, st, d, t.recT, t.keyT);
+    hipLaunchKernelGGL(k_feat0, g, dim3(256), 0, st, d, t.keyT);
 }
 
 void fer_launch_sort_radix(const FerDev &d, FerSortTmp &t, hipStream_t st)
@@ -685,8 +819,12 @@ void fer_launch_sort_radix(const FerDev &d, FerSortTmp &t, hipStream_t st)
     for (int pass = 0; pass < 2; pass++) {  // sum bits 0-6, then 7-13
         hipLaunchKernelGGL(k_rs_hist, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, t.keyT, t.dig2, hist, ntiles, pass);
         hipLaunchKernelGGL(k_rs_scan, dim3(d.S), dim3(256), 0, st, d, hist, ntiles);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, t.keyT, t.dig2, pass == 0 ? t.recT : t.rec1, t.rec1,
-                           t.dig2, t.rec_tmp, t.skey, hist, ntiles, pass);
+        if (pass == 0)
+            hipLaunchKernelGGL(k_rs_scatter<0>, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, t.dig2, t.rec1, t.rec1, t.dig2, t.rec_tmp, t.skey,
+                               hist, ntiles);
+        else
+            hipLaunchKernelGGL(k_rs_scatter<1>, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, t.dig2, t.rec1, t.rec1, t.dig2, t.rec_tmp, t.skey,
+                               hist, ntiles);
     }
 }
 
