@@ -11,15 +11,18 @@
 #include "fer_internal.h"
 
 // ------------------------------------------------------------------ k_interp
-// A workgroup = a 64 x 16 tile of the picture, a thread = four samples side by side of one row.  The tile and its
+// A workgroup = a 128 x 8 tile of the picture (a wavefront stores two full 128-byte lines per plane; 64 x 16 tiles
+// measured 3.33 ms per 256-stream picture against 3.09), a thread = four samples side by side of one row.  The tile and its
 // 2 / 3-sample apron sit in LDS shifted by two columns, so that the 12 bytes a thread needs of each of its six rows
 // (columns -2 .. +9 around its first sample) are three aligned dwords.  The nine vertical 6-tap values of columns
 // -2 .. +6 are shared by the four samples (the centre sample j filters them AFTER clipping, F/mocomp.cpp:71); every
 // plane gets one dword per thread.  Tiles are dealt so that one XCD owns a band of the picture: the apron rows a tile
 // shares with the tiles above and below are then fetched into one L2.
-#define IT_W 64
-#define IT_H 16
-#define IT_PITCH 72  // bytes of a tile row: 64 + 5 apron columns, rounded up to dwords
+#ifndef IT_W
+#define IT_W 128
+#define IT_H 8
+#endif
+#define IT_PITCH (IT_W + 8)  // bytes of a tile row: IT_W + 5 apron columns, rounded up to dwords
 __global__ __launch_bounds__(256) void k_interp(FerDev d)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[IT_H + 5][IT_PITCH];
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256) void k_interp(FerDev d)
         *(uint32_t *)&tile[r][c4] = v;
     }
     __syncthreads();
-    const int g = tid & 15, ty = tid >> 4;
+    const int g = tid % (IT_W / 4), ty = tid / (IT_W / 4);
     const int x = x0 + g * 4, y = y0 + ty;
     if (x >= W || y >= H) return;
     // rows y-2 .. y+3, columns x-2 .. x+6 (tv[r][k] = sample (x - 2 + k, y - 2 + r))
@@ -312,27 +315,34 @@ __global__ __launch_bounds__(256) void k_feat0(FerDev d, uint16_t *keyT)
 #define RS_BITS 7
 #define RS_ND (1 << RS_BITS)
 
-// digit of element idx for this pass: pass 0 = low 7 bits of the key, pass 1 = the high 7 bits kept by pass 0
-__device__ __forceinline__ unsigned rs_digit(const uint16_t *keyT, const uint8_t *dig2, int pass, size_t idx)
-{
-    return pass == 0 ? (unsigned)(keyT[idx] & (RS_ND - 1)) : (unsigned)dig2[idx];
-}
-
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(FerDev d, const uint16_t *keyT, const uint8_t *dig2, uint32_t *hist, int ntiles,
                                                        int pass)
 {
     __shared__ unsigned h[RS_ND];
     const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     if (d.hdr[s * 4 + 3] != 0) return;
-    const int n = d.W * d.H;
+    const int n = d.W * d.H;  // (a multiple of 256: a thread's RS_ITEMS = 8 consecutive items are all inside or all outside)
     const size_t g0 = (size_t)s * n;
     if (tid < RS_ND) h[tid] = 0;
+    static_assert(RS_ITEMS == 8, "one 16-byte / 8-byte load per thread");
+    const int idx = tile * RS_TILE + tid * RS_ITEMS;
+    const bool ok = idx < n;
+    unsigned dgs[RS_ITEMS];
+    if (pass == 0) {
+        const uint4 v = ok ? *(const uint4 *)(keyT + g0 + idx) : make_uint4(0, 0, 0, 0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < RS_ITEMS; i++) dgs[i] = (w[i >> 1] >> (16 * (i & 1))) & (RS_ND - 1);
+    } else {
+        const uint2 v = ok ? *(const uint2 *)(dig2 + g0 + idx) : make_uint2(0, 0);
+        const uint32_t w[2] = {v.x, v.y};
+#pragma unroll
+        for (int i = 0; i < RS_ITEMS; i++) dgs[i] = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
-        int idx = tile * RS_TILE + i * RS_THREADS + tid;
-        const bool ok = idx < n;
-        const unsigned dg = ok ? rs_digit(keyT, dig2, pass, g0 + idx) : 0u;
+        const unsigned dg = dgs[i];
         // flat content puts a whole wavefront on one digit: its lanes are counted with one atomic
         const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)dg);
         const unsigned long long same = __ballot(ok && dg == d0);
@@ -438,38 +448,53 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint8
         const int HR = H + 7;
         const float rHR = 1.0f / (float)HR, rH = 1.0f / (float)H;
         const bool shared_box = nc >= 3;
-        // sample (segment c, picture row r, first column of the segment) sits at smp[segb(c) + r * pitch]
-        const int pitch = shared_box ? (((xb + 7) >> 2) - (xa >> 2) + 1) * 4 : RS_SEG_PITCH;
+        // sample (segment c, picture row r, first column of the segment) sits at smp[segb(c) + r * pitch]; an odd number of
+        // dwords per row and an odd number of rows per thread (below) keep the lanes of a wavefront on different LDS banks
+        const int nd0 = ((xb + 7) >> 2) - (xa >> 2) + 1;
+        const int nd = shared_box ? (((nd0 | 1) * 4 * HR <= (int)sizeof(srec)) ? (nd0 | 1) : nd0) : RS_SEG_PITCH / 4;
+        const int pitch = nd * 4;
         const int rows0 = shared_box ? HR : (nc == 1 ? cnt + 7 : HR - ya);  // rows of the first box
-        // 1. samples
+        // 1. samples, eight loads in flight per thread
         {
-            const int nd = pitch / 4;
             const int nboxes = shared_box ? 1 : nc;
+            const float rnd = 1.0f / (float)nd;
             for (int bx = 0; bx < nboxes; bx++) {
                 const int nr = bx == 0 ? rows0 : (t0 + cnt - xb * H) + 7;  // the last segment starts at row 0
                 const int xs = (xa + bx) & ~3, r0 = (shared_box || bx) ? 0 : ya;
                 uint8_t *dst = smp + (bx ? rows0 * RS_SEG_PITCH : 0);
-                for (int i = tid; i < nr * nd; i += RS_THREADS) {
-                    unsigned r, c4;
-                    rs_divmod((unsigned)i, (unsigned)nd, 1.0f / (float)nd, r, c4);
-                    const int gx = xs + (int)c4 * 4, gy = min(r0 + (int)r, H - 1);
-                    const uint8_t *row = R + (size_t)gy * W;
-                    const uint32_t v = gx < W ? *(const uint32_t *)(row + gx) : (uint32_t)row[W - 1] * 0x01010101u;
-                    *(uint32_t *)(dst + (int)r * pitch + (int)c4 * 4) = v;
+                for (int i0 = 0; i0 < nr * nd; i0 += 8 * RS_THREADS) {
+                    uint32_t v[8];
+                    int at[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int i = i0 + k * RS_THREADS + tid;
+                        at[k] = -1;
+                        if (i < nr * nd) {
+                            unsigned r, c4;
+                            rs_divmod((unsigned)i, (unsigned)nd, rnd, r, c4);
+                            const int gx = xs + (int)c4 * 4, gy = min(r0 + (int)r, H - 1);
+                            const uint8_t *row = R + (size_t)gy * W;
+                            v[k] = gx < W ? *(const uint32_t *)(row + gx) : (uint32_t)row[W - 1] * 0x01010101u;
+                            at[k] = (int)r * pitch + (int)c4 * 4;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        if (at[k] >= 0) *(uint32_t *)(dst + at[k]) = v[k];
                 }
             }
         }
         __syncthreads();
         // 2. horizontal sums of a run of rows, prefix
-        const int L = (Q + RS_THREADS - 1) / RS_THREADS;  // <= 12 (H = 16: 257 segments)
+        const int L = ((Q + RS_THREADS - 1) / RS_THREADS) | 1;  // <= 13 (H = 16: 256 segments)
         const int q0 = min(tid * L, Q), q1 = min(q0 + L, Q);
-        unsigned long long hv[12];
+        unsigned long long hv[13];
         unsigned long long tot = 0;
         {
             unsigned c, r;
             rs_divmod((unsigned)(q0 + ya), (unsigned)HR, rHR, c, r);
 #pragma unroll
-            for (int k = 0; k < 12; k++) {
+            for (int k = 0; k < 13; k++) {
                 hv[k] = 0;
                 if (q0 + k < q1) {
                     int a;
@@ -504,7 +529,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint8
         unsigned long long pre = inc - tot;
         for (int w = 0; w < wv; w++) pre += wtot[w];
 #pragma unroll
-        for (int k = 0; k < 12; k++)
+        for (int k = 0; k < 13; k++)
             if (q0 + k < q1) {
                 PL[q0 + k] = pre;
                 pre += hv[k];
@@ -618,54 +643,80 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint8
 
 // Two-level bucket index over the plain sorted order.  Record i opens every (sum, column tile) bin after its
 // predecessor's up to its own: kol2[bin] = i for those bins (lower bound of the bin in the sorted order).  Gaps are
-// short except at the ends of the sum range; long ones are filled by the whole wavefront.
+// short except at the ends of the sum range; long ones are filled by the whole wavefront.  A thread takes SI_ITEMS
+// records (256 apart) and requests all of them before it looks at any: with one record per thread the kernel was one
+// memory round trip per wavefront and nothing else (2.5 ms per 256-stream picture for 7 GB).
+#define SI_ITEMS 4
 __global__ __launch_bounds__(256) void k_sort_index(FerDev d, const uint16_t *skey)
 {
     const int s = blockIdx.y;
     if (d.hdr[s * 4 + 3] != 0) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = d.W * d.H;
     const int nb = 16384 * d.kt;
     uint32_t *kol2 = d.kol2 + (size_t)s * nb;
     const size_t g0 = (size_t)s * n;
-    int gap_lo = 0, gap_hi = 0;  // bins [gap_lo, gap_hi) get value gval
-    uint32_t gval = 0;
-    if (i < n) {
-        const int bin = (int)skey[g0 + i] * d.kt + (int)((d.sort_pos[g0 + i] >> 16) >> d.ktw_shift);
-        int prev = -1;
-        if (i > 0) prev = (int)skey[g0 + i - 1] * d.kt + (int)((d.sort_pos[g0 + i - 1] >> 16) >> d.ktw_shift);
-        gap_lo = prev + 1;
-        gap_hi = bin + 1;
-        gval = (uint32_t)(g0 + i);
-        // the first record of a bucket clears what the big-bucket kernels accumulate for it (ranges, modal class), and a
-        // record whose key is still the same 1024 places on says "this stream has big buckets" for this picture
-        const int key = (int)skey[g0 + i];
-        if (i == 0 || (int)skey[g0 + i - 1] != key) {
-            uint4 *br = (uint4 *)(d.brange + ((size_t)s * 16384 + key) * 8);
-            br[0] = make_uint4(0, 0, 0, 0);
-            br[1] = make_uint4(0, 0, 0, 0);
-            *(uint4 *)(d.bmodal + ((size_t)s * 16384 + key) * 4) = make_uint4(0, 0, 0, 0);
+    const int lane = threadIdx.x & 63;
+    int key[SI_ITEMS], pkey[SI_ITEMS], fkey[SI_ITEMS];
+    uint32_t pos[SI_ITEMS], ppos[SI_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SI_ITEMS; k++) {
+        const int i = (blockIdx.x * SI_ITEMS + k) * 256 + (int)threadIdx.x;
+        key[k] = pkey[k] = fkey[k] = -1;
+        pos[k] = ppos[k] = 0;
+        if (i < n) {
+            key[k] = (int)skey[g0 + i];
+            pos[k] = d.sort_pos[g0 + i];
+            if (lane == 0 && i > 0) {  // (the other lanes take the predecessor from their neighbour)
+                pkey[k] = (int)skey[g0 + i - 1];
+                ppos[k] = d.sort_pos[g0 + i - 1];
+            }
+            if (i + FER_BRANGE_MIN < n) fkey[k] = (int)skey[g0 + i + FER_BRANGE_MIN];
         }
-        if (i + FER_BRANGE_MIN < n && (int)skey[g0 + i + FER_BRANGE_MIN] == key) d.nbig[s] = d.serial;
     }
-    // the last record also closes the index: every bin after its own, and the end marker, start at the segment end
-    const bool tail = i == n - 1;
-    for (int pass = 0; pass < 2; pass++) {
-        if (pass == 1) {
-            if (!__any(tail)) break;
-            gap_lo = tail ? gap_hi : 0;
-            gap_hi = tail ? nb + 1 : 0;
-            gval = (uint32_t)(g0 + n);
+#pragma unroll
+    for (int k = 0; k < SI_ITEMS; k++) {
+        const int i = (blockIdx.x * SI_ITEMS + k) * 256 + (int)threadIdx.x;
+        int gap_lo = 0, gap_hi = 0;  // bins [gap_lo, gap_hi) get value gval
+        uint32_t gval = 0;
+        const int nkey = __shfl_up(key[k], 1);
+        const uint32_t npos = (uint32_t)__shfl_up((int)pos[k], 1);
+        if (i < n) {
+            const int pk = lane ? nkey : pkey[k];
+            const uint32_t pp = lane ? npos : ppos[k];
+            const int bin = key[k] * d.kt + (int)((pos[k] >> 16) >> d.ktw_shift);
+            const int prev = i > 0 ? pk * d.kt + (int)((pp >> 16) >> d.ktw_shift) : -1;
+            gap_lo = prev + 1;
+            gap_hi = bin + 1;
+            gval = (uint32_t)(g0 + i);
+            // the first record of a bucket clears what the big-bucket kernels accumulate for it (ranges, modal class), and a
+            // record whose key is still the same 1024 places on says "this stream has big buckets" for this picture
+            if (i == 0 || pk != key[k]) {
+                uint4 *br = (uint4 *)(d.brange + ((size_t)s * 16384 + key[k]) * 8);
+                br[0] = make_uint4(0, 0, 0, 0);
+                br[1] = make_uint4(0, 0, 0, 0);
+                *(uint4 *)(d.bmodal + ((size_t)s * 16384 + key[k]) * 4) = make_uint4(0, 0, 0, 0);
+            }
+            if (fkey[k] == key[k]) d.nbig[s] = d.serial;
         }
-        unsigned long long big = __ballot(gap_hi - gap_lo > 8);
-        if (gap_hi - gap_lo <= 8)
-            for (int b = gap_lo; b < gap_hi; b++) kol2[b] = gval;
-        while (big) {
-            int src = __ffsll((long long)big) - 1;
-            big &= big - 1;
-            int lo = __shfl(gap_lo, src), hi = __shfl(gap_hi, src);
-            uint32_t val = (uint32_t)__shfl((int)gval, src);
-            for (int b = lo + (threadIdx.x & 63); b < hi; b += 64) kol2[b] = val;
+        // the last record also closes the index: every bin after its own, and the end marker, start at the segment end
+        const bool tail = i == n - 1;
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1) {
+                if (!__any(tail)) break;
+                gap_lo = tail ? gap_hi : 0;
+                gap_hi = tail ? nb + 1 : 0;
+                gval = (uint32_t)(g0 + n);
+            }
+            unsigned long long big = __ballot(gap_hi - gap_lo > 8);
+            if (gap_hi - gap_lo <= 8)
+                for (int b = gap_lo; b < gap_hi; b++) kol2[b] = gval;
+            while (big) {
+                int src = __ffsll((long long)big) - 1;
+                big &= big - 1;
+                int lo = __shfl(gap_lo, src), hi = __shfl(gap_hi, src);
+                uint32_t val = (uint32_t)__shfl((int)gval, src);
+                for (int b = lo + lane; b < hi; b += 64) kol2[b] = val;
+            }
         }
     }
 }
@@ -679,12 +730,12 @@ __global__ __launch_bounds__(256) void k_sort_index(FerDev d, const uint16_t *sk
 //    from it, and their sorted-array indices (list number = the bucket's first place / FER_BRANGE_MIN: unique, since every
 //    big bucket has more places than that).  A wavefront counts its outliers with one atomic per bucket it touches and stops
 //    adding once the bucket is known to have too many.
-__global__ __launch_bounds__(256) void k_bucket_classes(FerDev d, const uint16_t *skey)
+// Both kernels of this kind below usually have nothing to do for a stream (no big bucket, no sum-0 position): a stream
+// gets SF_BLOCKS workgroups that loop over its records, not one workgroup per 256 records that exits at once (the empty
+// launches alone took 1.7 ms per 256-stream picture).
+#define SF_BLOCKS 64
+__device__ __forceinline__ void bucket_classes_records(const FerDev &d, const uint16_t *skey, int s, int i)
 {
-    const int s = blockIdx.y;
-    if (d.nbig[s] != d.serial) return;  // (k_sort_index of this picture)
-    if (d.hdr[s * 4 + 3] != 0 || d.zero_cnt[s] != 0) return;  // (a stream with sum-0 positions: its crowded partitions take the exact slow path)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = d.W * d.H;
     const size_t g0 = (size_t)s * n;
     const uint32_t *kol2 = d.kol2 + (size_t)s * 16384 * d.kt;
@@ -743,6 +794,14 @@ __global__ __launch_bounds__(256) void k_bucket_classes(FerDev d, const uint16_t
         }
     }
 }
+__global__ __launch_bounds__(256) void k_bucket_classes(FerDev d, const uint16_t *skey)
+{
+    const int s = blockIdx.y;
+    if (d.nbig[s] != d.serial) return;  // (k_sort_index of this picture)
+    if (d.hdr[s * 4 + 3] != 0 || d.zero_cnt[s] != 0) return;  // (a stream with sum-0 positions: its crowded partitions take the exact slow path)
+    const int nblk = (d.W * d.H + 255) / 256;
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) bucket_classes_records(d, skey, s, blk * 256 + (int)threadIdx.x);
+}
 
 // Bucket 0.  The reference's counting sort (F/moestimation.cpp:153-172) leaves bucket 0 out of its prefix sum: with
 // n0 positions of sum 0, every other bucket starts n0 places early (the sorted array is the other positions from 0,
@@ -758,10 +817,9 @@ __global__ __launch_bounds__(256) void k_sort_quirk(FerDev d, const uint32_t *re
     if (d.hdr[s * 4 + 3] != 0) return;
     const int n0 = d.zero_cnt[s];
     if (n0 == 0) return;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;  // place of the final array
     const int n = d.W * d.H;
-    if (p >= n) return;
     const size_t g0 = (size_t)s * n;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {  // place of the final array
     const int ir = p + n0;   // the regular position that lands here (sorted index), if any
     const int iz = p - n0;   // the sum-0 position aimed here, if any
     const bool hr = ir < n, hz = iz >= 0 && iz < n0;
@@ -775,12 +833,13 @@ __global__ __launch_bounds__(256) void k_sort_quirk(FerDev d, const uint32_t *re
     } else if (hz) {
         src = iz;
     }
-    if (src < 0) return;  // keeps the previous picture's entry
+    if (src < 0) continue;  // keeps the previous picture's entry
     const uint32_t *in = rec_tmp + (g0 + src) * 3;
     uint32_t *o = d.sort_rec + (g0 + p) * 3;
     o[0] = in[0];
     o[1] = in[1];
     o[2] = in[2];
+    }
 }
 
 size_t fer_sort_tmp_bytes(int n, int S)
@@ -832,9 +891,10 @@ void fer_launch_sort_radix(const FerDev &d, FerSortTmp &t, hipStream_t st)
 void fer_launch_sort_finish(const FerDev &d, FerSortTmp &t, hipStream_t st)
 {
     const int n = d.W * d.H;
-    hipLaunchKernelGGL(k_sort_index, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
-    hipLaunchKernelGGL(k_bucket_classes, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.skey);
-    hipLaunchKernelGGL(k_sort_quirk, dim3((n + 255) / 256, d.S), dim3(256), 0, st, d, t.rec_tmp);
+    hipLaunchKernelGGL(k_sort_index, dim3((n + 256 * SI_ITEMS - 1) / (256 * SI_ITEMS), d.S), dim3(256), 0, st, d, t.skey);
+    const int sfb = std::min((n + 255) / 256, SF_BLOCKS);
+    hipLaunchKernelGGL(k_bucket_classes, dim3(sfb, d.S), dim3(256), 0, st, d, t.skey);
+    hipLaunchKernelGGL(k_sort_quirk, dim3(sfb, d.S), dim3(256), 0, st, d, t.rec_tmp);
 }
 
 void fer_launch_sort(const FerDev &d, FerSortTmp &t, hipStream_t st)

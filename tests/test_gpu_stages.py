@@ -29,8 +29,11 @@ def test_block_transform_kat(pkg, fo):
             assert np.array_equal(inverse_residual(qp, lv, keep), fo.inverse_residual(qp, lv, keep)), (qp, keep)
 
 
-def test_refprep_matches_oracle(pkg, fo):
-    f0, f1 = _two_frames(pkg)
+# the sizes beside QCIF put a tile of the first radix pass (4096 positions in column order, k_rs_scatter<0>) on 256 columns
+# (H = 16), on two or three (H = 2064) and on one or two columns of a picture taller than a tile
+@pytest.mark.parametrize("W,H", [(176, 144), (1024, 16), (32, 2064), (16, 4112), (208, 80)])
+def test_refprep_matches_oracle(pkg, fo, W, H):
+    f0, f1 = _two_frames(pkg, W, H)
     o = fo.Oracle(W, H, qp=12, window=16)
     o.set_dpb(f0)
     o.fill_interpolated()
