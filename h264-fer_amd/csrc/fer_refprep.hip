@@ -454,33 +454,59 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint8
         const int nd = shared_box ? (((nd0 | 1) * 4 * HR <= (int)sizeof(srec)) ? (nd0 | 1) : nd0) : RS_SEG_PITCH / 4;
         const int pitch = nd * 4;
         const int rows0 = shared_box ? HR : (nc == 1 ? cnt + 7 : HR - ya);  // rows of the first box
-        // 1. samples, eight loads in flight per thread
+        // 1. samples: a thread fetches whole rows of a narrow box (two rows = up to 14 dwords in flight), single dwords of
+        //    a wide one (pictures of a few rows)
         {
             const int nboxes = shared_box ? 1 : nc;
-            const float rnd = 1.0f / (float)nd;
             for (int bx = 0; bx < nboxes; bx++) {
                 const int nr = bx == 0 ? rows0 : (t0 + cnt - xb * H) + 7;  // the last segment starts at row 0
                 const int xs = (xa + bx) & ~3, r0 = (shared_box || bx) ? 0 : ya;
                 uint8_t *dst = smp + (bx ? rows0 * RS_SEG_PITCH : 0);
-                for (int i0 = 0; i0 < nr * nd; i0 += 8 * RS_THREADS) {
-                    uint32_t v[8];
-                    int at[8];
+                if (nd <= 7) {
+                    const bool inside = xs + nd * 4 <= W;
+                    for (int ra = tid; ra < nr; ra += 2 * RS_THREADS) {
+                        uint32_t v[2][7];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int i = i0 + k * RS_THREADS + tid;
-                        at[k] = -1;
-                        if (i < nr * nd) {
-                            unsigned r, c4;
-                            rs_divmod((unsigned)i, (unsigned)nd, rnd, r, c4);
-                            const int gx = xs + (int)c4 * 4, gy = min(r0 + (int)r, H - 1);
-                            const uint8_t *row = R + (size_t)gy * W;
-                            v[k] = gx < W ? *(const uint32_t *)(row + gx) : (uint32_t)row[W - 1] * 0x01010101u;
-                            at[k] = (int)r * pitch + (int)c4 * 4;
+                        for (int k = 0; k < 2; k++) {
+                            const int r = ra + k * RS_THREADS;
+                            const uint8_t *row = R + (size_t)min(r0 + min(r, nr - 1), H - 1) * W;
+                            const uint32_t last = inside ? 0u : (uint32_t)row[W - 1] * 0x01010101u;
+#pragma unroll
+                            for (int j = 0; j < 7; j++)
+                                if (j < nd) v[k][j] = (inside || xs + j * 4 < W) ? *(const uint32_t *)(row + xs + j * 4) : last;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const int r = ra + k * RS_THREADS;
+                            if (r < nr) {
+#pragma unroll
+                                for (int j = 0; j < 7; j++)
+                                    if (j < nd) *(uint32_t *)(dst + r * pitch + j * 4) = v[k][j];
+                            }
                         }
                     }
+                } else {
+                    const float rnd = 1.0f / (float)nd;
+                    for (int i0 = 0; i0 < nr * nd; i0 += 8 * RS_THREADS) {
+                        uint32_t v[8];
+                        int at[8];
 #pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        if (at[k] >= 0) *(uint32_t *)(dst + at[k]) = v[k];
+                        for (int k = 0; k < 8; k++) {
+                            const int i = i0 + k * RS_THREADS + tid;
+                            at[k] = -1;
+                            if (i < nr * nd) {
+                                unsigned r, c4;
+                                rs_divmod((unsigned)i, (unsigned)nd, rnd, r, c4);
+                                const int gx = xs + (int)c4 * 4, gy = min(r0 + (int)r, H - 1);
+                                const uint8_t *row = R + (size_t)gy * W;
+                                v[k] = gx < W ? *(const uint32_t *)(row + gx) : (uint32_t)row[W - 1] * 0x01010101u;
+                                at[k] = (int)r * pitch + (int)c4 * 4;
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                            if (at[k] >= 0) *(uint32_t *)(dst + at[k]) = v[k];
+                    }
                 }
             }
         }
@@ -537,14 +563,22 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint8
         if (q0 < Q && q1 == Q) PL[Q] = pre;
         __syncthreads();
         // 3. the items of this thread
+        unsigned x = 0, y = 0;
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; r++) {
             const int idx = w0 + r * 64 + lane;
             dg[r] = 0;
             rec[r] = make_uint4(0, 0, 0, 0);
+            if (r == 0 || H < 64) {
+                rs_divmod((unsigned)min(idx, n - 1), (unsigned)H, rH, x, y);
+            } else {  // 64 positions on: at most one column further
+                y += 64;
+                if (y >= (unsigned)H) {
+                    y -= (unsigned)H;
+                    x++;
+                }
+            }
             if (idx < n) {
-                unsigned x, y;
-                rs_divmod((unsigned)idx, (unsigned)H, rH, x, y);
                 const int c = (int)x - xa;
                 const int q = c * HR + (int)y - ya;  // row y of segment c
                 const unsigned long long p0 = PL[q], p8 = PL[q + 8];
