@@ -353,30 +353,41 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(FerDev d, const uint16_t
     if (tid < RS_ND) hist[((size_t)s * RS_ND + tid) * ntiles + tile] = h[tid];  // digit-major: the scan order is the output order
 }
 
-__global__ __launch_bounds__(256) void k_rs_scan(FerDev d, uint32_t *hist, int ntiles)
+// exclusive scan of one stream's (digit, tile) counts: sixteen wavefronts, each over a contiguous sixteenth of the table,
+// four counts per lane and step (the table length is a multiple of RS_ND, so of four)
+#define RSS_WAVES 16
+__global__ __launch_bounds__(64 * RSS_WAVES) void k_rs_scan(FerDev d, uint32_t *hist, int ntiles)
 {
-    __shared__ unsigned part[256];
-    const int s = blockIdx.x, tid = threadIdx.x;
+    __shared__ unsigned wtot[RSS_WAVES];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (d.hdr[s * 4 + 3] != 0) return;
-    uint32_t *h = hist + (size_t)s * RS_ND * ntiles;
-    const int n = RS_ND * ntiles;
-    const int per = (n + 255) / 256;
-    const int b0 = min(tid * per, n), b1 = min(b0 + per, n);
+    uint4 *h4 = (uint4 *)(hist + (size_t)s * RS_ND * ntiles);
+    const int n4 = RS_ND * ntiles / 4;
+    const int per = (n4 + RSS_WAVES - 1) / RSS_WAVES;
+    const int u0 = min(wv * per, n4), u1 = min(u0 + per, n4);
     unsigned sum = 0;
-    for (int i = b0; i < b1; i++) sum += h[i];
-    part[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        unsigned v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    for (int u = u0 + lane; u < u1; u += 64) {
+        const uint4 v = h4[u];
+        sum += v.x + v.y + v.z + v.w;
     }
-    unsigned run = tid ? part[tid - 1] : 0;
-    for (int i = b0; i < b1; i++) {
-        unsigned v = h[i];
-        h[i] = run;
-        run += v;
+    sum = (unsigned)wave_sum((int)sum);
+    if (lane == 0) wtot[wv] = sum;
+    __syncthreads();
+    unsigned carry = 0;
+    for (int w = 0; w < wv; w++) carry += wtot[w];
+    for (int ub = u0; ub < u1; ub += 64) {
+        const int u = ub + lane;
+        const uint4 v = u < u1 ? h4[u] : make_uint4(0, 0, 0, 0);
+        const unsigned t = v.x + v.y + v.z + v.w;
+        unsigned inc = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned x = __shfl_up(inc, o);
+            if (lane >= o) inc += x;
+        }
+        const unsigned ex = carry + inc - t;
+        if (u < u1) h4[u] = make_uint4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
+        carry += __shfl(inc, 63);
     }
 }
 
@@ -911,7 +922,7 @@ void fer_launch_sort_radix(const FerDev &d, FerSortTmp &t, hipStream_t st)
     uint32_t *hist = (uint32_t *)t.tmp;
     for (int pass = 0; pass < 2; pass++) {  // sum bits 0-6, then 7-13
         hipLaunchKernelGGL(k_rs_hist, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, t.keyT, t.dig2, hist, ntiles, pass);
-        hipLaunchKernelGGL(k_rs_scan, dim3(d.S), dim3(256), 0, st, d, hist, ntiles);
+        hipLaunchKernelGGL(k_rs_scan, dim3(d.S), dim3(64 * RSS_WAVES), 0, st, d, hist, ntiles);
         if (pass == 0)
             hipLaunchKernelGGL(k_rs_scatter<0>, dim3(ntiles, d.S), dim3(RS_THREADS), 0, st, d, t.dig2, t.rec1, t.rec1, t.dig2, t.rec_tmp, t.skey,
                                hist, ntiles);
