@@ -111,6 +111,12 @@ __device__ __forceinline__ bool db_more(const DecBits &b) { return (b.pos >> 3) 
 // look-ups by the next bits of the stream (coeff_token: 16 bits, total_zeros: 9, run_before: 3).
 // entry = len << 8 | value, 0 = no code matches; coeff_token value = TotalCoeff << 2 | TrailingOnes.
 #define DEC_CT_SUBS 48
+// One coefficient level per look-up (level_prefix + level_suffix, F/residual.cpp:1183-1262) by the next DEC_LEV_BITS bits
+// of the stream and the decoder state: states 0..6 = suffixLength, 7 / 8 = suffixLength 0 / 1 at the first level after
+// fewer than three trailing ones (levelCode + 2).  entry = bits | next suffixLength << 4 | level << 7 (signed 9 bits),
+// 0 = the code does not fit the window (long prefixes, escapes): the arithmetic path decodes it.
+#define DEC_LEV_BITS 11
+#define DEC_LEV_STATES 9
 struct DecLuts {
     uint16_t ct[4][65536];   // class 0..2 by nC, 3 = chroma DC: the full 16-bit look-up (build step only)
     // what the parse kernel keeps in LDS: coeff_token in two levels of 8 bits
@@ -119,6 +125,7 @@ struct DecLuts {
     uint16_t tz[15][512];    // by TotalCoeff - 1
     uint16_t tzdc[3][8];
     uint16_t rb[6][8];       // by zerosLeft - 1 (zerosLeft <= 6)
+    uint16_t lev[DEC_LEV_STATES][1 << DEC_LEV_BITS];
     int nsub;
 };
 struct DecLutsLds {  // the same tables, resident in LDS for one parse wavefront
@@ -127,6 +134,7 @@ struct DecLutsLds {  // the same tables, resident in LDS for one parse wavefront
     uint16_t tz[15][512];
     uint16_t tzdc[3][8];
     uint16_t rb[6][8];
+    uint16_t lev[DEC_LEV_STATES][1 << DEC_LEV_BITS];
 };
 static DecLuts *g_dec_luts = nullptr;
 
@@ -169,6 +177,25 @@ __global__ void k_dec_build_luts(DecLuts *L)
             L->ct[cls][v] = e;
         }
     }
+    if (v < (1u << DEC_LEV_BITS))
+        for (int st = 0; st < DEC_LEV_STATES; st++) {
+            const int sl = st < 7 ? st : st - 7;
+            uint16_t e = 0;
+            if (v != 0) {
+                const int prefix = __clz((int)v) - (32 - DEC_LEV_BITS);  // < 14: no escape, the suffix has sl bits
+                const int total = prefix + 1 + sl;
+                if (total <= DEC_LEV_BITS) {
+                    const int suffix = (int)((v >> (DEC_LEV_BITS - total)) & ((1u << sl) - 1u));
+                    int levelCode = (prefix << sl) + suffix;
+                    if (st >= 7) levelCode += 2;
+                    const int lev = (levelCode & 1) == 0 ? (levelCode + 2) >> 1 : (-levelCode - 1) >> 1;
+                    int nsl = sl == 0 ? 1 : sl;
+                    if (iabs(lev) > (3 << (nsl - 1)) && nsl < 6) nsl++;
+                    e = (uint16_t)(total | (nsl << 4) | ((lev & 0x1ff) << 7));
+                }
+            }
+            L->lev[st][v] = e;
+        }
     if (v < 512)
         for (int tcm1 = 0; tcm1 < 15; tcm1++) {
             uint16_t e = 0;
@@ -207,9 +234,9 @@ __global__ void k_dec_build_luts(DecLuts *L)
     }
 }
 
-// residual_block_cavlc, F/residual.cpp:1069-1386.  coef: int16 destination (maxNumCoeff entries,
-// already zero).  lvl/rn: 16-entry scratch in LDS.  Returns TotalCoeff, or -1 on a malformed block.
-__device__ int dec_block(DecBits &b, const DecLutsLds *L, int16_t *coef, int maxNumCoeff, int nC, int16_t *lvl, uint8_t *rn)
+// residual_block_cavlc, F/residual.cpp:1069-1386.  coef: int16 destination (maxNumCoeff entries, already zero).
+// The levels of the block live in one vector register (lane i = level i), the runs in a scalar 64-bit word.  Returns TotalCoeff, or -1 on a malformed block.
+__device__ int dec_block(DecBits &b, const DecLutsLds *L, int16_t *coef, int maxNumCoeff, int nC)
 {
     int TotalCoeff, TrailingOnes = 0;
     if (nC >= 8) {
@@ -232,11 +259,21 @@ __device__ int dec_block(DecBits &b, const DecLutsLds *L, int16_t *coef, int max
     }
     if (TotalCoeff == 0) return 0;
     if (TotalCoeff > maxNumCoeff) return -1;
+    const int lane = (int)(threadIdx.x & 63);
+    int lvv = 0;
+    if (TrailingOnes) {  // the sign bits of the trailing ones, first coefficient first
+        const unsigned sg = db_bits(b, TrailingOnes);
+        lvv = 1 - 2 * (int)((sg >> ((TrailingOnes - 1 - lane) & 31)) & 1u);
+    }
     int suffixLength = (TotalCoeff > 10 && TrailingOnes < 3) ? 1 : 0;
-    for (int i = 0; i < TotalCoeff; i++) {
+    int st = TrailingOnes < 3 ? 7 + suffixLength : suffixLength;
+    for (int i = TrailingOnes; i < TotalCoeff; i++) {
         int lev;
-        if (i < TrailingOnes) {
-            lev = 1 - 2 * (int)db_bit(b);
+        const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)L->lev[st][db_peek(b, DEC_LEV_BITS)]);
+        if (e) {
+            db_skip(b, e & 15u);
+            lev = ((int)(e << 16)) >> 23;
+            suffixLength = (int)((e >> 4) & 7u);
         } else {
             const unsigned w = db_peek(b, 32);
             if (w == 0) return -1;  // level_prefix beyond 31
@@ -247,12 +284,13 @@ __device__ int dec_block(DecBits &b, const DecLutsLds *L, int16_t *coef, int max
             int levelCode = (min(prefix, 15) << suffixLength);
             if (size > 0 || prefix >= 14) levelCode += (int)suffix;
             if (prefix >= 15 && suffixLength == 0) levelCode += 15;
-            if (i == TrailingOnes && TrailingOnes < 3) levelCode += 2;
+            if (st >= 7) levelCode += 2;
             lev = (levelCode & 1) == 0 ? (levelCode + 2) >> 1 : (-levelCode - 1) >> 1;
             if (suffixLength == 0) suffixLength = 1;
             if (iabs(lev) > (3 << (suffixLength - 1)) && suffixLength < 6) suffixLength++;
         }
-        lvl[i] = (int16_t)lev;
+        st = suffixLength;
+        lvv = lane == i ? lev : lvv;
     }
     int zerosLeft = 0;
     if (TotalCoeff < maxNumCoeff) {
@@ -263,42 +301,38 @@ __device__ int dec_block(DecBits &b, const DecLutsLds *L, int16_t *coef, int max
         zerosLeft = (int)(e & 0xff);
     }
     unsigned long long runs = 0;  // run_before of coefficient j in bits 4j..4j+3 (scalar registers, no LDS round trips)
-    for (int j = 0; j < TotalCoeff - 1; j++) {
-        int rb = 0;
-        if (zerosLeft > 0) {
-            if (zerosLeft > 6) {
-                rb = 7 - (int)db_bits(b, 3);
-                if (rb == 7) {
-                    const unsigned w = db_peek(b, 32);
-                    if (w == 0) return -1;
-                    const int z = __clz((int)w);
-                    db_skip(b, (unsigned)(z + 1));
-                    rb += z;
-                }
-            } else {
-                const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)L->rb[zerosLeft - 1][db_peek(b, 3)]);
-                if (e == 0) return -1;
-                db_skip(b, e >> 8);
-                rb = (int)(e & 0xff);
+    int j = 0;
+    for (; j < TotalCoeff - 1 && zerosLeft > 0; j++) {  // (no zeros left: every further run is 0)
+        int rb;
+        if (zerosLeft > 6) {
+            rb = 7 - (int)db_bits(b, 3);
+            if (rb == 7) {
+                const unsigned w = db_peek(b, 32);
+                if (w == 0) return -1;
+                const int z = __clz((int)w);
+                db_skip(b, (unsigned)(z + 1));
+                rb += z;
             }
+        } else {
+            const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)L->rb[zerosLeft - 1][db_peek(b, 3)]);
+            if (e == 0) return -1;
+            db_skip(b, e >> 8);
+            rb = (int)(e & 0xff);
         }
         runs |= (unsigned long long)(rb & 15) << (4 * j);
         zerosLeft -= rb;
     }
     runs |= (unsigned long long)(max(zerosLeft, 0) & 15) << (4 * (TotalCoeff - 1));
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     {  // placement, one coefficient per lane: position of coefficient i = sum over k >= i of (run_k + 1), minus 1
-        const int i = (int)(threadIdx.x & 63);
+        const int i = lane;
         if (i < TotalCoeff) {
             unsigned long long x = runs >> (4 * i);
             unsigned long long sm = (x & 0x0f0f0f0f0f0f0f0full) + ((x >> 4) & 0x0f0f0f0f0f0f0f0full);
             unsigned s32 = (unsigned)sm + (unsigned)(sm >> 32);
             int pos = (TotalCoeff - i) - 1 + (int)((s32 * 0x01010101u) >> 24);
-            if (pos < maxNumCoeff) coef[pos] = lvl[i];
+            if (pos < maxNumCoeff) coef[pos] = (int16_t)lvv;
         }
     }
-    (void)rn;
     return TotalCoeff;
 }
 
@@ -437,8 +471,6 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
 {
     __shared__ uint8_t tcur_w[DEC_PW][24];
     __shared__ int16_t cac_w[DEC_PW][2][4][16];  // ChromaACLevel persists across macroblocks (reference quirk)
-    __shared__ int16_t lvl_w[DEC_PW][16];
-    __shared__ uint8_t rn_w[DEC_PW][16];
     __shared__ __attribute__((aligned(16))) int16_t mblv_w[DEC_PW][FER_LEVELS];  // levels of the macroblock being parsed
     __shared__ DecLutsLds lut;
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
@@ -446,8 +478,6 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
     DecNb *row = (DecNb *)dyn_lds + (size_t)wv * d.mbw;  // [mbw] per wavefront
     uint8_t *tcur = tcur_w[wv];
     int16_t(*cac)[4][16] = cac_w[wv];
-    int16_t *lvl = lvl_w[wv];
-    uint8_t *rn = rn_w[wv];
     int16_t *mblv = mblv_w[wv];
     {  // decode tables into LDS, once per workgroup
         const uint32_t *src = (const uint32_t *)&luts->ct1[0][0];
@@ -628,7 +658,7 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
             if (mb_qp_delta < -26 || mb_qp_delta > 25) bad = true;
             // residual(0,15), F/residual.cpp:959-1067
             if (i16 && !bad) {
-                int n = dec_block(b, &lut, lv + FER_LV_DC16, 16, dec_nC(row, mbx, mby, true, 0, 0, tcur, cbpL, cbpC), lvl, rn);
+                int n = dec_block(b, &lut, lv + FER_LV_DC16, 16, dec_nC(row, mbx, mby, true, 0, 0, tcur, cbpL, cbpC));
                 bad |= n < 0;
                 if (n >= 0) tcur[0] = (uint8_t)n;
                 DEC_WSYNC();
@@ -637,19 +667,19 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
                 if (cbpL & (1 << i8))
                     for (int i4x = 0; i4x < 4 && !bad; i4x++) {
                         int blk = i8 * 4 + i4x;
-                        int n = dec_block(b, &lut, lv + blk * 16, i16 ? 15 : 16, dec_nC(row, mbx, mby, true, blk, 0, tcur, cbpL, cbpC), lvl, rn);
+                        int n = dec_block(b, &lut, lv + blk * 16, i16 ? 15 : 16, dec_nC(row, mbx, mby, true, blk, 0, tcur, cbpL, cbpC));
                         bad |= n < 0;
                         if (n >= 0) tcur[blk] = (uint8_t)n;
                         DEC_WSYNC();
                     }
             for (int pl = 0; pl < 2 && !bad; pl++)
-                if (cbpC & 3) bad |= dec_block(b, &lut, lv + FER_LV_CDC + pl * 4, 4, -1, lvl, rn) < 0;
+                if (cbpC & 3) bad |= dec_block(b, &lut, lv + FER_LV_CDC + pl * 4, 4, -1) < 0;
             for (int pl = 0; pl < 2 && !bad; pl++)
                 for (int cb = 0; cb < 4 && !bad; cb++) {
                     if (cbpC & 2) {
                         for (int i = lane; i < 16; i += 64) cac[pl][cb][i] = 0;
                         DEC_WSYNC();
-                        int n = dec_block(b, &lut, &cac[pl][cb][0], 15, dec_nC(row, mbx, mby, false, cb, pl, tcur, cbpL, cbpC), lvl, rn);
+                        int n = dec_block(b, &lut, &cac[pl][cb][0], 15, dec_nC(row, mbx, mby, false, cb, pl, tcur, cbpL, cbpC));
                         bad |= n < 0;
                         if (n >= 0) tcur[16 + pl * 4 + cb] = (uint8_t)n;
                         DEC_WSYNC();

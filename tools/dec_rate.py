@@ -1,0 +1,26 @@
+"""Dev helper (GPU box): the 1080p decode leg of bench.py's secondary configurations alone."""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+import bench
+pkg = bench.load_pkg() if hasattr(bench, "load_pkg") else None
+if pkg is None:
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
+    from conftest import load_pkg
+    pkg = load_pkg()
+from h264_fer_amd.synth import gen_frames_torch
+dev = torch.device("cuda:0")
+W, H, S, T = 1920, 1072, 16, 30
+fr = gen_frames_torch(W, H, T, S, dev, seed=1234, noise=2).cpu().numpy()
+e = pkg.FerHip(W, H, S, qp=12, window=32, maxdiff=3, intra_every=30)
+streams, _ = e.encode_streams(fr)
+nmb = e.nmb
+e.close()
+batch = streams * 8
+pkg.decode_streams(batch, T, want_pictures=False)
+for _ in range(2):
+    t0 = time.perf_counter()
+    _, pics, _, _ = pkg.decode_streams(batch, T, want_pictures=False)
+    dt = time.perf_counter() - t0
+    print("decode MB/s", round(len(batch) * T * nmb / dt, 1), "all", pics == [T] * len(batch), flush=True)
