@@ -22,49 +22,57 @@
 #include "fer_intra_dev.h"
 #include "fer_mvpred.h"
 
-// Bit reader over one slice: a 64-bit window of the stream starting at the 32-bit aligned position wbase
-// (big-endian), refilled 32 bits at a time from a word that was requested one refill earlier, so the parse
-// loop never waits for memory per syntax element.  Everything is wave-uniform (scalar registers / scalar loads).
+// Bit reader over one slice: a 64-bit window of the stream starting at the 32-bit aligned position wbase (big-endian),
+// refilled 32 bits at a time.  The stream itself comes in through a 512-byte ring in LDS, one coalesced 256-byte load of
+// the whole wavefront per 2 048 bits: a refill is then a DS read, not a trip to memory (a dword requested from memory
+// one refill ahead was waited for on the spot all the same -- the copy into the loop-carried register needs the data).
+// Position, window and everything derived from them are wave-uniform (scalar registers).
 struct DecBits {
-    const uint8_t *buf;
+    const uint8_t *buf;  // 4-byte aligned; the slice buffers are padded by 16 bytes
     unsigned size;  // bytes
     unsigned pos;   // bit position
     unsigned long long win;  // stream bits [wbase, wbase + 64)
     unsigned wbase;          // multiple of 32, pos - wbase < 32
-    unsigned nxt;            // the dword behind the window, requested but not yet looked at (raw, little-endian)
+    uint32_t *ring;          // [128] dwords of this wavefront in LDS: stream bytes [256 c, 256 c + 256) in half c & 1
 };
 
-// raw little-endian dword at `byte` (clamped into the buffer): requested early, consumed by db_take
-__device__ __forceinline__ unsigned db_fetch(const DecBits &b, unsigned byte)
+// chunk c of the stream into its half of the ring (addresses clamped into the padded buffer)
+__device__ __forceinline__ void db_chunk(const DecBits &b, unsigned c)
 {
-    unsigned a = min(byte, (b.size + 3u) & ~3u);  // the slice buffers are padded by 16 bytes
-    return *(const uint32_t *)(b.buf + a);
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned a = min(c * 256u + lane * 4u, (b.size + 3u) & ~3u);
+    const uint32_t v = *(const uint32_t *)(b.buf + a);
+    b.ring[((c & 1u) << 6) + lane] = v;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
-// ... as big-endian stream bits, zero past the end.  The value is the same in every lane: taking it into a scalar
-// register (only now, when the load has long returned) moves the whole reader to the scalar unit.
-__device__ __forceinline__ unsigned db_take(const DecBits &b, unsigned raw, unsigned byte)
+// the dword at byte offset `byte` (a multiple of 4) as big-endian stream bits, zero past the end of the slice
+__device__ __forceinline__ unsigned db_dword(const DecBits &b, unsigned byte)
 {
-    unsigned v = __builtin_bswap32((unsigned)__builtin_amdgcn_readfirstlane((int)raw));
+    unsigned v = __builtin_bswap32((unsigned)__builtin_amdgcn_readfirstlane((int)b.ring[(byte >> 2) & 127u]));
     if (byte + 4 > b.size) v = byte >= b.size ? 0u : (v & ~(0xffffffffu >> (8 * (b.size - byte))));
     return v;
 }
-__device__ __forceinline__ void db_open(DecBits &b, const uint8_t *buf, unsigned size, unsigned pos)
+__device__ __forceinline__ void db_open(DecBits &b, const uint8_t *buf, unsigned size, unsigned pos, uint32_t *ring)
 {
     b.buf = buf;
     b.size = size;
     b.pos = pos;
+    b.ring = ring;
     b.wbase = pos & ~31u;
     const unsigned by = b.wbase >> 3;
-    b.win = ((unsigned long long)db_take(b, db_fetch(b, by), by) << 32) | db_take(b, db_fetch(b, by + 4), by + 4);
-    b.nxt = db_fetch(b, by + 8);
+    db_chunk(b, by >> 8);
+    if (((by + 4) >> 8) != (by >> 8)) db_chunk(b, (by + 4) >> 8);
+    b.win = ((unsigned long long)db_dword(b, by) << 32) | db_dword(b, by + 4);
 }
 __device__ __forceinline__ void db_skip(DecBits &b, unsigned n)  // n <= 32
 {
     b.pos += n;
     if (b.pos - b.wbase >= 32) {
-        b.win = (b.win << 32) | db_take(b, b.nxt, (b.wbase >> 3) + 8);
+        const unsigned by = (b.wbase >> 3) + 8;
+        if ((by & 255u) == 0) db_chunk(b, by >> 8);
+        b.win = (b.win << 32) | db_dword(b, by);
         b.wbase += 32;
-        b.nxt = db_fetch(b, (b.wbase >> 3) + 8);
     }
 }
 __device__ __forceinline__ unsigned db_peek(const DecBits &b, int n)  // 1 <= n <= 32
@@ -459,17 +467,19 @@ __device__ void dec_derive_mvs(const FerDev &d, short *mvs, const int *mbt, int 
 // residual (reference quirks) -- changes no bit position, so every picture is parsed as if it inherited zeros;
 // it reports how many macroblocks ran on the inherited delta and flags those that show the inherited block,
 // k_dec_carry hands the true values down the pictures of a stream and k_dec_patch applies them.
-#ifndef DEC_PW
-#define DEC_PW 8
-#endif  // pictures (wavefronts) per workgroup: they share the decode tables in LDS
+// PW pictures (wavefronts) per workgroup share the decode tables in LDS; the launch takes the largest PW whose tables,
+// per-wavefront scratch and neighbour rows fit the CU's 160 KB (16 at 1080p: the scalar chains of 16 pictures hide
+// each other's table round trips, 8 left the scalar unit half idle).
 #define DEC_WSYNC()                                        \
     do {                                                   \
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
         __builtin_amdgcn_wave_barrier();                   \
     } while (0)
+template <int DEC_PW>
 __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B, const DecLuts *__restrict__ luts)
 {
     __shared__ uint8_t tcur_w[DEC_PW][24];
+    __shared__ uint32_t ring_w[DEC_PW][128];  // the bit reader's window on the stream
     __shared__ int16_t cac_w[DEC_PW][2][4][16];  // ChromaACLevel persists across macroblocks (reference quirk)
     __shared__ __attribute__((aligned(16))) int16_t mblv_w[DEC_PW][FER_LEVELS];  // levels of the macroblock being parsed
     __shared__ DecLutsLds lut;
@@ -485,22 +495,34 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
         for (int i = threadIdx.x; i < (int)(sizeof(DecLutsLds) / 4); i += 64 * DEC_PW) dst[i] = src[i];
         __syncthreads();
     }
-    const size_t pic = (size_t)blockIdx.x * DEC_PW + wv;  // index of this picture in the window's [TW][S] arrays
-    if (pic >= (size_t)B.TW * d.S) return;
+    // Pictures are handed out through a counter (B.state[2] of the window's first picture, cleared by the launch): the
+    // I pictures of the window's first step -- the longest scalar chains of the launch -- go out first, one to each
+    // workgroup in turn (so to different CUs), and a wavefront that has finished a short P picture takes the next one
+    // instead of idling beside an I picture until the workgroup ends.
+    for (;;) {
+    size_t pic;
+    {
+        int tk = 0;
+        if (lane == 0) tk = atomicAdd(&B.state[2], 1);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk >= (int)gridDim.x * DEC_PW) break;
+#ifdef DEC_TICKET_PLAIN
+        pic = (size_t)tk;
+#else
+        pic = (size_t)(tk % DEC_PW) * gridDim.x + (size_t)(tk / DEC_PW);  // ticket -> picture: DEC_PW consecutive tickets are gridDim.x pictures apart
+#endif
+    }
+    if (pic >= (size_t)B.TW * d.S) continue;
     const int tpic = (int)(pic / d.S), s = (int)(pic % d.S);
     const uint32_t *info = B.info + pic * 6;
-    {  // this picture's slice of the side information
-        const size_t o = (size_t)tpic * d.S * d.nmb;
-        d.mb_type = B.mb_type + o;
-        d.mv = B.mv + o * 8;
-        d.cbp = B.cbp + o * 2;
-        d.tc = B.tc + o * 24;
-        d.i4mode = B.i4mode + o * 16;
-        d.i4flag = B.i4flag + o * 16;
-        d.chroma_mode = B.chroma_mode + o;
-        d.levels = B.levels + o * FER_LEVELS;
-        d.dec_qp = B.dec_qp + o;
-    }
+    // this picture's slice of the side information (the kernel argument d itself is never written: a modified copy of
+    // that 900-byte structure would live in scratch memory)
+    const size_t po = (size_t)tpic * d.S * d.nmb;
+    int *const p_mb_type = B.mb_type + po;
+    short *const p_mv = B.mv + po * 8;
+    uint8_t *const p_cbp = B.cbp + po * 2, *const p_tc = B.tc + po * 24, *const p_i4mode = B.i4mode + po * 16;
+    uint8_t *const p_i4flag = B.i4flag + po * 16, *const p_chroma_mode = B.chroma_mode + po, *const p_dec_qp = B.dec_qp + po;
+    int16_t *const p_levels = B.levels + po * FER_LEVELS;
     uint8_t *carry = B.carry + pic * d.nmb;
     int *st = B.state + pic * 4, *summ = B.summ + pic * 4;
     // the slice parameters are the same in every lane: scalar registers, so that everything derived from them
@@ -509,6 +531,12 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
     const unsigned i_pos = (unsigned)__builtin_amdgcn_readfirstlane((int)info[1]);
     const int i_slice = __builtin_amdgcn_readfirstlane((int)info[2]);
     const int stype = i_slice & 255;
+#ifndef DEC_NOPRIO
+    if (stype == 2)  // the critical path of the launch goes first
+        __builtin_amdgcn_s_setprio(3);
+    else
+        __builtin_amdgcn_s_setprio(0);
+#endif
     // ref_idx_l0 is parsed and dropped (every prediction uses the one stored picture): in sub_mb_pred the reference
     // reads it when the slice carried num_ref_idx_active_override_flag, in mb_pred when the active count left behind
     // by the last override is > 1 (F/rbsp_decoding.cpp:156-161, :217-221)
@@ -519,14 +547,14 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
             st[1] = 0;
             summ[0] = summ[3] = 0;
         }
-        return;
+        continue;
     }
     const bool constrained_intra = __builtin_amdgcn_readfirstlane((int)B.hdr[pic * 4 + 1]) != 0;
     DecBits b;
-    db_open(b, B.rbsp + (((size_t)i_hi << 32) | i_lo), i_size, i_pos);
+    db_open(b, B.rbsp + (((size_t)i_hi << 32) | i_lo), i_size, i_pos, ring_w[wv]);
     int QPy = __builtin_amdgcn_readfirstlane((int)info[3]);
-    int *mbt = d.mb_type + (size_t)s * d.nmb;
-    short *mvs = d.mv + (size_t)s * d.nmb * 8;
+    int *mbt = p_mb_type + (size_t)s * d.nmb;
+    short *mvs = p_mv + (size_t)s * d.nmb * 8;
     int mb_qp_delta = 0;  // the inherited value is added by k_dec_patch
     bool delta_known = false, cac_known = false;
     int n_inherit = 0;    // macroblocks whose QP step used the inherited delta
@@ -559,7 +587,7 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
                 dec_derive_mvs(d, mvs, mbt, cur, FER_P_SKIP, mvd, sub);
                 QPy = (QPy + mb_qp_delta + 52) % 52;
                 n_inherit += delta_known ? 0 : 1;
-                d.dec_qp[mbi] = (uint8_t)QPy;
+                p_dec_qp[mbi] = (uint8_t)QPy;
                 if (lane == 0) carry[cur] = 0;
                 cur++;
             }
@@ -623,7 +651,7 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
                 for (int blk = 0; blk < 16; blk++) {
                     int f = (int)db_bit(b);
                     int rem = f ? 0 : (int)db_bits(b, 3);
-                    d.i4flag[mbi * 16 + blk] = (uint8_t)((f << 3) | rem);
+                    p_i4flag[mbi * 16 + blk] = (uint8_t)((f << 3) | rem);
                 }
             chroma_mode = (int)db_ue(b);
             if (chroma_mode > 3) {
@@ -645,9 +673,9 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
             cbpC = ((k - 1) / 4) % 3;
             cbpL = k >= 13 ? 15 : 0;
         }
-        d.cbp[mbi * 2] = (uint8_t)cbpL;
-        d.cbp[mbi * 2 + 1] = (uint8_t)cbpC;
-        d.chroma_mode[mbi] = (uint8_t)chroma_mode;
+        p_cbp[mbi * 2] = (uint8_t)cbpL;
+        p_cbp[mbi * 2 + 1] = (uint8_t)cbpC;
+        p_chroma_mode[mbi] = (uint8_t)chroma_mode;
         for (int i = lane; i < 24; i += 64) tcur[i] = 0;
         DEC_WSYNC();
         DP_MARK(0)
@@ -700,11 +728,11 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
         for (int i = lane; i < 120; i += 64) lv[FER_LV_CAC + i] = cac[i / 60][(i % 60) / 15][i % 15];
         DEC_WSYNC();
         {  // the finished macroblock: levels to memory (one coalesced pass), counts into the neighbour row
-            uint32_t *g = (uint32_t *)(d.levels + mbi * FER_LEVELS);
+            uint32_t *g = (uint32_t *)(p_levels + mbi * FER_LEVELS);
             for (int i = lane; i < FER_LEVELS / 2; i += 64) g[i] = ((const uint32_t *)mblv)[i];
             DecNb &me = row[mbx];
             if (lane < 24) {
-                d.tc[mbi * 24 + lane] = tcur[lane];
+                p_tc[mbi * 24 + lane] = tcur[lane];
                 me.tc[lane] = tcur[lane];
             }
             if (lane == 0) {
@@ -716,7 +744,7 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
         DEC_WSYNC();
         QPy = (QPy + mb_qp_delta + 52) % 52;
         n_inherit += delta_known ? 0 : 1;
-        d.dec_qp[mbi] = (uint8_t)QPy;
+        p_dec_qp[mbi] = (uint8_t)QPy;
         if (inter) {
             dec_derive_mvs(d, mvs, mbt, cur, t, mvd, sub);
         } else if (i4) {
@@ -730,13 +758,13 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
                     int ma = edgeA ? cur - 1 : cur, mb2 = edgeB ? cur - d.mbw : cur;
                     int ta = mbt[ma], tb = mbt[mb2];
                     bool a4 = stype == 2 ? ta == 0 : ta == 5, b4 = stype == 2 ? tb == 0 : tb == 5;
-                    mA = a4 ? d.i4mode[((size_t)s * d.nmb + ma) * 16 + c_nbA[blk]] : 2;
-                    mB = b4 ? d.i4mode[((size_t)s * d.nmb + mb2) * 16 + c_nbB[blk]] : 2;
+                    mA = a4 ? p_i4mode[((size_t)s * d.nmb + ma) * 16 + c_nbA[blk]] : 2;
+                    mB = b4 ? p_i4mode[((size_t)s * d.nmb + mb2) * 16 + c_nbB[blk]] : 2;
                 }
                 int pm = mA <= mB ? mA : mB;
-                int f = d.i4flag[mbi * 16 + blk];
+                int f = p_i4flag[mbi * 16 + blk];
                 int mode = (f & 8) ? pm : ((f & 7) < pm ? (f & 7) : (f & 7) + 1);
-                d.i4mode[mbi * 16 + blk] = (uint8_t)mode;
+                p_i4mode[mbi * 16 + blk] = (uint8_t)mode;
             }
         }
         more = db_more(b);
@@ -759,6 +787,8 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
         summ[2] = n_inherit;
         summ[3] = cac_known;
     }
+    DEC_WSYNC();
+    }  // next picture
 }
 
 // per stream, down the pictures of the window: what each picture inherits (FerDev.dec_state / dec_cac hold the
@@ -1012,8 +1042,26 @@ void fer_launch_decode_parse(const FerDev &d, const DecBatch &B, hipStream_t st)
         hipLaunchKernelGGL(k_dec_build_luts, dim3(256), dim3(256), 0, st, g_dec_luts);
         hipLaunchKernelGGL(k_dec_split_luts, dim3(4), dim3(256), 0, st, g_dec_luts);
     }
-    hipLaunchKernelGGL(k_dec_parse, dim3((d.S * B.TW + DEC_PW - 1) / DEC_PW), dim3(64 * DEC_PW), (size_t)DEC_PW * d.mbw * sizeof(DecNb), st, d, B,
-                       g_dec_luts);
+    // static LDS of k_dec_parse<PW>: the tables + PW * (tcur 24 + stream ring 512 + ChromaACLevel 256 + the macroblock's levels); dynamic: the rows
+    const size_t fixed = sizeof(DecLutsLds), per_wave = 24 + 512 + 256 + FER_LEVELS * 2 + (size_t)d.mbw * sizeof(DecNb);
+    const int npic = d.S * B.TW;
+#define DEC_PARSE_LAUNCH(PW)                                                                                                          \
+    hipLaunchKernelGGL(k_dec_parse<PW>, dim3((npic + PW - 1) / PW), dim3(64 * PW), (size_t)PW * d.mbw * sizeof(DecNb), st, d, B, \
+                       g_dec_luts)
+    const size_t lds = 160 * 1024 - 512;
+    hipMemsetAsync(B.state + 2, 0, sizeof(int), st);
+#ifndef DEC_MAXPW
+#define DEC_MAXPW 16
+#endif
+    if (DEC_MAXPW >= 16 && fixed + 16 * per_wave <= lds)
+        DEC_PARSE_LAUNCH(16);
+    else if (fixed + 8 * per_wave <= lds)
+        DEC_PARSE_LAUNCH(8);
+    else if (fixed + 4 * per_wave <= lds)
+        DEC_PARSE_LAUNCH(4);
+    else
+        DEC_PARSE_LAUNCH(1);
+#undef DEC_PARSE_LAUNCH
     hipLaunchKernelGGL(k_dec_carry, dim3(d.S), dim3(128), 0, st, d, B);
     hipLaunchKernelGGL(k_dec_patch, dim3((d.nmb + 255) / 256, d.S, B.TW), dim3(256), 0, st, d, B);
 }

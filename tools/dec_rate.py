@@ -17,10 +17,12 @@ e = pkg.FerHip(W, H, S, qp=12, window=32, maxdiff=3, intra_every=30)
 streams, _ = e.encode_streams(fr)
 nmb = e.nmb
 e.close()
-batch = streams * 8
-pkg.decode_streams(batch, T, want_pictures=False)
-for _ in range(2):
-    t0 = time.perf_counter()
-    _, pics, _, _ = pkg.decode_streams(batch, T, want_pictures=False)
-    dt = time.perf_counter() - t0
-    print("decode MB/s", round(len(batch) * T * nmb / dt, 1), "all", pics == [T] * len(batch), flush=True)
+for reps in [int(a) for a in sys.argv[1:]] or [8]:
+    batch = streams * reps
+    pkg.decode_streams(batch, T, want_pictures=False)
+    for _ in range(2):
+        t0 = time.perf_counter()
+        _, pics, _, _ = pkg.decode_streams(batch, T, want_pictures=False)
+        dt = time.perf_counter() - t0
+        print("streams", len(batch), "decode MB/s", round(len(batch) * T * nmb / dt, 1), "s", round(dt, 3), "all", pics == [T] * len(batch), flush=True)
+    pkg.load_library().ferhip_decode_release()
