@@ -52,8 +52,10 @@ CONFIGS = {
 # HBM bytes per second against the 6.29 TB/s a copy reaches, VALU / scalar instructions against their issue rates).
 KERNELS = {
     "interp": ("k_interp", 256 + 16 * 256, "P"),
-    "sort_keys": ("k_feat0", 256 + 256 * (12 + 16 + 2), "P"),
-    "sort": ("k_rs_hist+k_rs_scan+k_rs_scatter (two radix passes)", 256 * (2 + 1 + 2 + 16 + 16 + 1 + 1 + 16 + 12 + 4 + 2), "P"),
+    "sort_keys": ("k_feat0", 256 + 256 * (12 + 2), "P"),  # luma in; row-major plane-0 records + keys in arrival order out
+    # pass 1: keys 2 (histogram) + luma 1 in, records 16 + high digit 1 out; pass 2: digit 1 + 1, records 16 in, walk records 12 +
+    # positions 4 + keys 2 out
+    "sort": ("k_rs_hist+k_rs_scan+k_rs_scatter (two radix passes)", 256 * (2 + 1 + 16 + 1 + 1 + 1 + 16 + 12 + 4 + 2), "P"),
     "sort_finish": ("k_sort_index+k_bucket_classes+k_sort_quirk", 256 * 6 + 1956, "P"),
     "me_pre": ("k_me_pre", ME_BYTES_PER_MB, "P"),
     "me_walk": ("k_me_walk", ME_BYTES_PER_MB, "P"),

@@ -506,11 +506,7 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
         if (lane == 0) tk = atomicAdd(&B.state[2], 1);
         tk = __builtin_amdgcn_readfirstlane(tk);
         if (tk >= (int)gridDim.x * DEC_PW) break;
-#ifdef DEC_TICKET_PLAIN
-        pic = (size_t)tk;
-#else
         pic = (size_t)(tk % DEC_PW) * gridDim.x + (size_t)(tk / DEC_PW);  // ticket -> picture: DEC_PW consecutive tickets are gridDim.x pictures apart
-#endif
     }
     if (pic >= (size_t)B.TW * d.S) continue;
     const int tpic = (int)(pic / d.S), s = (int)(pic % d.S);
@@ -531,12 +527,6 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
     const unsigned i_pos = (unsigned)__builtin_amdgcn_readfirstlane((int)info[1]);
     const int i_slice = __builtin_amdgcn_readfirstlane((int)info[2]);
     const int stype = i_slice & 255;
-#ifndef DEC_NOPRIO
-    if (stype == 2)  // the critical path of the launch goes first
-        __builtin_amdgcn_s_setprio(3);
-    else
-        __builtin_amdgcn_s_setprio(0);
-#endif
     // ref_idx_l0 is parsed and dropped (every prediction uses the one stored picture): in sub_mb_pred the reference
     // reads it when the slice carried num_ref_idx_active_override_flag, in mb_pred when the active count left behind
     // by the last override is > 1 (F/rbsp_decoding.cpp:156-161, :217-221)
@@ -1050,10 +1040,7 @@ void fer_launch_decode_parse(const FerDev &d, const DecBatch &B, hipStream_t st)
                        g_dec_luts)
     const size_t lds = 160 * 1024 - 512;
     hipMemsetAsync(B.state + 2, 0, sizeof(int), st);
-#ifndef DEC_MAXPW
-#define DEC_MAXPW 16
-#endif
-    if (DEC_MAXPW >= 16 && fixed + 16 * per_wave <= lds)
+    if (fixed + 16 * per_wave <= lds)
         DEC_PARSE_LAUNCH(16);
     else if (fixed + 8 * per_wave <= lds)
         DEC_PARSE_LAUNCH(8);

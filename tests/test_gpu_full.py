@@ -404,6 +404,22 @@ def test_gpu_decoder_1080p(pkg, fo):
     assert np.array_equal(out[:, 0], rec[:, 0])  # decoder output == encoder reconstruction
 
 
+@pytest.mark.parametrize("W,H,S", [(3840, 64, 3), (6400, 32, 2), (12800, 16, 1)])
+def test_gpu_decoder_wide_pictures(pkg, fo, W, H, S):
+    """The parse kernel keeps a row of neighbour context per picture in LDS and is instantiated for 16, 8, 4 or 1 pictures
+    per workgroup, whichever fits: 240, 400 and 800 macroblocks per row take the 8, 4 and 1 instantiations (1080p: 16)."""
+    T = 3
+    frames = np.stack([np.stack([pkg.gen_frame(W, H, t, 77 + s, 2) for s in range(S)]) for t in range(T)])
+    g = pkg.FerHip(W, H, S, qp=20, window=16, maxdiff=3, intra_every=30)
+    streams, rec = g.encode_streams(frames, want_recon=True)
+    assert g.status() == [0] * S
+    g.close()
+    out, pics, w, h = pkg.decode_streams(streams, T)
+    assert pics == [T] * S and (w, h) == (W, H)
+    assert np.array_equal(out, rec)  # decoder output == encoder reconstruction
+    assert np.array_equal(out[:, 0], _oracle_decode(fo, streams[0]))
+
+
 def test_gpu_decoder_reproduces_reference_md5_on_drugi(pkg):
     """The reference's own fixture F/drugi.264 (x264 baseline, 640x480, 1000 pictures, intra MBs in P
     slices, mb_qp_delta != 0) decoded on the GPU gives the md5 of the REFERENCE's output recorded in

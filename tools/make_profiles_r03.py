@@ -71,8 +71,8 @@ def load(path, counter):
 fa, fc = load(newest(str(go / "pmc_fetch/*/*_counter_collection.csv")), "FETCH_SIZE")
 wa, wc = load(newest(str(go / "pmc_write/*/*_counter_collection.csv")), "WRITE_SIZE")
 S = 16
-alg = {"k_interp": 4352, "k_feat0": 256 + 256 * 30, "k_me_pre": 528, "k_me_walk": 528, "k_me_spec": 528, "k_me_resolve": 528, "k_p_resid": 1152,
-       "k_intra_mb": 768, "k_cavlc": 800, "k_frame_sad": 512, "k_rs_scatter": 256 * 33}
+alg = {"k_interp": 4352, "k_feat0": 256 + 256 * 14, "k_me_pre": 528, "k_me_walk": 528, "k_me_spec": 528, "k_me_resolve": 528, "k_p_resid": 1152,
+       "k_intra_mb": 768, "k_cavlc": 800, "k_frame_sad": 512, "k_rs_scatter<0>": 256 * 18, "k_rs_scatter<1>": 256 * 35}
 tmd = ["# Round 3 — HBM traffic counters (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes)", "",
        "`rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 tools/quick_hd.py 16 2` (and `WRITE_SIZE`): 1080p, 16 streams, I+P, two encodes.",
        "FETCH_SIZE / WRITE_SIZE are in KiB; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, the "
@@ -85,7 +85,7 @@ for k in sorted(fa, key=lambda k: -fa[k]):
     n = fc[k]
     f = fa[k] * 1024 / n / 1e6
     w = wa.get(k, 0) * 1024 / max(wc.get(k, 1), 1) / 1e6
-    per_pic = 254 if k.startswith("k_intra") else (2 if k.startswith("k_rs_") else 1)
+    per_pic = 254 if k.startswith("k_intra") else (2 if k.startswith(("k_rs_hist", "k_rs_scan")) else 1)
     bpm = (2 * f + w) * 1e6 * per_pic / (S * NMB)
     a = [v for kk, v in alg.items() if k.startswith(kk)]
     tmd.append("| `%s` | %d | %d | %.2f | %.2f | %.2f | %.0f | %s |" % (k[:40], n, per_pic, f, 2 * f, w, bpm, a[0] if a else ""))
@@ -136,7 +136,7 @@ smd += ["", "For a per-macroblock kernel multiply by 4 (k_p_resid: the line abov
 
 # limiter of every phase: the largest of (HBM bytes/s : 6.29 TB/s), (VALU wave instructions x 4 cycles : SIMD cycles), (scalar
 # instructions : one per CU cycle), each over the kernel's duration in the benchmark run; below 0.5 everywhere = latency
-phase_kernels = {"interp": ["k_interp", "k_interp_pad"], "sort_keys": ["k_feat0"], "sort": ["k_rs_hist", "k_rs_scan", "k_rs_scatter"],
+phase_kernels = {"interp": ["k_interp", "k_interp_pad"], "sort_keys": ["k_feat0"], "sort": ["k_rs_hist", "k_rs_scan", "k_rs_scatter<0>", "k_rs_scatter<1>"],
                  "sort_finish": ["k_sort_index", "k_bucket_classes", "k_sort_quirk"], "me_pre": ["k_me_pre<32>"], "me_walk": ["k_me_walk"],
                  "me_spec": ["k_me_spec<32>"], "me_resolve": ["k_me_resolve<32>"], "p_resid": ["k_p_resid"], "intra": ["k_intra_mb"],
                  "cavlc": ["k_cavlc<false>", "k_bits_scan", "k_cavlc<true>"], "frame_sad": ["k_frame_sad"]}
@@ -145,7 +145,7 @@ for ph, ks in phase_kernels.items():
     t = 0.0
     valu = salu = 0.0
     for k in ks:
-        per_pic = 254 if k.startswith("k_intra") else (2 if k.startswith("k_rs_") else 1)
+        per_pic = 254 if k.startswith("k_intra") else (2 if k.startswith(("k_rs_hist", "k_rs_scan")) else 1)
         t += avg_ns.get(k, 0.0) * 1e-9 * per_pic / (S_BENCH * NMB)          # seconds per macroblock
         if k in inst:
             valu += inst[k][0] * 4 * per_pic
@@ -182,3 +182,19 @@ print("bench", b1["value"])
 print("traffic", bytes_per_mb)
 print("limiter", limiter)
 print("fractions", fracs)
+
+# decode leg
+try:
+    drows = list(csv.DictReader(open(newest(str(go / "dec/*/*_kernel_stats.csv")))))
+    rates = [l.strip() for l in open(go / "dec.log") if l.startswith("streams")]
+    dmd = ["# Round 3 — rocprofv3 kernel summary of the 1080p decode leg", "",
+           "`rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/dec_rate.py 8`: 128 streams x one 30-picture GOP of the "
+           "encoder's own 1080p IPPP output (bench.py's secondary configuration), decoded three times (one warm-up).", "",
+           "Rates printed by the same run: " + "; ".join(rates), "",
+           "| kernel | calls | total ms | avg us |", "|---|---|---|---|"]
+    for r in drows:
+        if "k_dec" in r["Name"]:
+            dmd.append("| `%s` | %s | %.1f | %.1f |" % (r["Name"][:60], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3))
+    (prof / "r03_kernel_stats_decode.md").write_text("\n".join(dmd) + "\n")
+except Exception as e:  # the decode pass is optional
+    print("decode profile skipped:", e)
