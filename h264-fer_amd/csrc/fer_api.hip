@@ -1309,9 +1309,16 @@ static int dec_parse_slice_header(DecHdr &h, const uint8_t *rbsp, size_t n, int 
 }
 
 // split an Annex-B stream like findNALstart/findNALend/parseNAL (4-byte start codes only)
+struct ByteView {  // bytes owned elsewhere: a stream's RBSP store (split_stream) or the caller's buffer (ferhip_dec_nal)
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+};
 struct NalRef {
     int type, ref_idc;
-    std::vector<uint8_t> rbsp;
+    ByteView rbsp;
 };
 // next position i in [from, n - 2) with s[i] == 0, s[i+1] == 0 and s[i+2] in `third` (two allowed values), or npos;
 // zero bytes are rare in entropy-coded data, so the scan is driven by memchr
@@ -1326,8 +1333,11 @@ static size_t find_zz(const uint8_t *s, size_t from, size_t n, uint8_t t0, uint8
     }
     return (size_t)-1;
 }
-static void split_stream(const uint8_t *s, size_t n, std::vector<NalRef> &out)
+// `store` receives the RBSP of every NAL unit back to back (never more than the stream itself) and must outlive `out`
+static void split_stream(const uint8_t *s, size_t n, std::vector<NalRef> &out, std::vector<uint8_t> &store)
 {
+    if (store.size() < n) store.resize(n);
+    uint8_t *w = store.data();
     size_t pos = 0;
     for (;;) {
         size_t st = (size_t)-1;
@@ -1348,15 +1358,21 @@ static void split_stream(const uint8_t *s, size_t n, std::vector<NalRef> &out)
         NalRef nal;
         nal.ref_idc = (s[st] & 0x7f) >> 5;
         nal.type = s[st] & 0x1f;
-        nal.rbsp.reserve(en - st);
+        uint8_t *w0 = w;
         size_t from = st + 1;
         for (;;) {  // drop the emulation prevention byte of every 00 00 03
             size_t z = find_zz(s, from, en, 3, 3);
             if (z == (size_t)-1) break;
-            nal.rbsp.insert(nal.rbsp.end(), s + from, s + z + 2);
+            memcpy(w, s + from, z + 2 - from);
+            w += z + 2 - from;
             from = z + 3;
         }
-        if (from < en) nal.rbsp.insert(nal.rbsp.end(), s + from, s + en);
+        if (from < en) {
+            memcpy(w, s + from, en - from);
+            w += en - from;
+        }
+        nal.rbsp.p = w0;
+        nal.rbsp.n = (size_t)(w - w0);
         if (nal.rbsp.empty()) break;
         out.push_back(std::move(nal));
     }
@@ -1375,6 +1391,7 @@ struct DecArena {
 };
 static DecArena g_dec_arena;
 static std::mutex g_dec_arena_mu;
+static thread_local std::vector<std::vector<uint8_t>> tl_rbsp_store;  // ferhip_decode_streams: the streams' RBSP, per calling thread
 static void dec_arena_free(DecArena *a)
 {
     if (a->dev) hipFree(a->dev);
@@ -1439,6 +1456,7 @@ static void dec_arena_release(DecArena *a)
 
 extern "C" int ferhip_decode_release(void)
 {
+    std::vector<std::vector<uint8_t>>().swap(tl_rbsp_store);
     std::lock_guard<std::mutex> lk(g_dec_arena_mu);
     if (g_dec_arena.busy) return FERHIP_E_STATE;
     if (g_dec_arena.device >= 0) {
@@ -1722,12 +1740,17 @@ extern "C" int ferhip_decode_streams(const uint8_t *const *streams, const size_t
     const bool verbose = getenv("FER_DEC_TIMING") != nullptr;
     double t_start = dec_now();
     std::vector<std::vector<NalRef>> nals(S);
+    // the RBSP of every stream, kept by the calling thread between calls like the device arena: 240 MB of fresh heap per
+    // call (128 1080p GOPs) cost 0.25 s in page faults and unmapping, a fifth of the decode itself
+    std::vector<std::vector<uint8_t>> &rbsp_store = tl_rbsp_store;
+    if ((int)rbsp_store.size() < S) rbsp_store.resize(S);
     {  // NAL splitting is host work per stream: spread it over a few threads
         const int nth = std::max(1, std::min(std::min(S, 16), (int)std::thread::hardware_concurrency()));
         std::vector<std::thread> th;
+        std::vector<std::vector<uint8_t>> &store = rbsp_store;
         for (int k = 0; k < nth; k++)
             th.emplace_back([&, k]() {
-                for (int s = k; s < S; s += nth) split_stream(streams[s], lens[s], nals[s]);
+                for (int s = k; s < S; s += nth) split_stream(streams[s], lens[s], nals[s], store[s]);
             });
         for (auto &x : th) x.join();
     }
@@ -1847,7 +1870,8 @@ extern "C" int ferhip_dec_nal(ferhip_dec *dc, int nal_unit_type, int nal_ref_idc
         NalRef nal;
         nal.type = nal_unit_type;
         nal.ref_idc = nal_ref_idc;
-        nal.rbsp.assign(rbsp, rbsp + n);
+        nal.rbsp.p = rbsp;
+        nal.rbsp.n = n;
         std::vector<std::vector<const NalRef *>> slices(1);
         slices[0].push_back(&nal);
         int rc = dec_session_window(dc->ss, slices, 0, 1, picture, nullptr);

@@ -470,12 +470,21 @@ def decode_streams(streams, max_pictures, want_pictures=True):
     lens = (C.c_size_t * S)(*[len(s) for s in streams])
     pics = (C.c_int * S)()
     W, H = C.c_int(), C.c_int()
-    from . import shard
-    sps = [n for n in shard.split_nals(streams[0]) if (n[4] & 31) == 7][0]
-    w, h = _sps_size(sps[5:])
     if max_pictures <= 0:
         raise FerHipError("decode_streams: max_pictures must be positive (it sizes the output)")
-    out = np.empty((max_pictures, S, w * h * 3 // 2), np.uint8) if want_pictures else None
+    out = None
+    if want_pictures:  # the output is sized from the first SPS of stream 0 (found by start code, not by splitting the stream)
+        at = 0
+        while True:
+            at = streams[0].find(b"\x00\x00\x01", at)
+            if at < 0 or at + 3 >= len(streams[0]):
+                raise FerHipError("decode_streams: no sequence parameter set in stream 0")
+            at += 3
+            if (streams[0][at] & 31) == 7:
+                break
+        end = streams[0].find(b"\x00\x00\x01", at)
+        w, h = _sps_size(streams[0][at + 1:end if end >= 0 else len(streams[0])].replace(b"\x00\x00\x03", b"\x00\x00"))
+        out = np.empty((max_pictures, S, w * h * 3 // 2), np.uint8)
     _chk(lib.ferhip_decode_streams(arr, lens, S, out.ctypes.data if want_pictures else None, max_pictures, pics,
                                    C.byref(W), C.byref(H)), "ferhip_decode_streams")
     return out, list(pics), W.value, H.value
