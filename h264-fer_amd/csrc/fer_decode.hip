@@ -348,7 +348,7 @@ __device__ int dec_block(DecBits &b, const DecLutsLds *L, int16_t *coef, int max
 // column holds the macroblock above until the current one replaces it (so entry x - 1 is the left neighbour).
 struct DecNb {
     uint8_t tc[24];
-    uint8_t cbpL, cbpC, skip, pad;
+    uint8_t cbpL, cbpC, skip, i4;  // i4: an Intra4x4 macroblock (its bottom-row prediction modes are in the i4row entry)
 };
 // nC of F/residual.cpp:424-538 (wave-uniform)
 __device__ int dec_nC(const DecNb *row, int x, int y, bool luma, int blk, int plane, const uint8_t *tcur, int cbpL, int cbpC)
@@ -486,6 +486,10 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     DecNb *row = (DecNb *)dyn_lds + (size_t)wv * d.mbw;  // [mbw] per wavefront
+    // Intra4x4PredMode of blocks 10, 11, 14, 15 of the macroblock above, 4 bits each: getIntra4x4PredMode reads its neighbours
+    // from here and from scalar registers, not from the mode array in memory (16 dependent round trips per macroblock)
+    uint16_t *i4row = (uint16_t *)((DecNb *)dyn_lds + (size_t)DEC_PW * d.mbw) + (size_t)wv * d.mbw;
+    unsigned long long left_modes = 0;  // the modes of the last Intra4x4 macroblock parsed (the left neighbour when its i4 flag says so)
     uint8_t *tcur = tcur_w[wv];
     int16_t(*cac)[4][16] = cac_w[wv];
     int16_t *mblv = mblv_w[wv];
@@ -572,7 +576,10 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
             for (int i = 0; i < run && cur < d.nmb; i++) {
                 size_t mbi = (size_t)s * d.nmb + cur;
                 mbt[cur] = FER_P_SKIP;
-                if (lane == 0) row[cur % d.mbw].skip = 1;
+                if (lane == 0) {
+                    row[cur % d.mbw].skip = 1;
+                    row[cur % d.mbw].i4 = 0;
+                }
                 for (int k = 0; k < 4; k++) mvd[k][0] = mvd[k][1] = 0;  // ClearMVD in PredictMV
                 dec_derive_mvs(d, mvs, mbt, cur, FER_P_SKIP, mvd, sub);
                 QPy = (QPy + mb_qp_delta + 52) % 52;
@@ -603,6 +610,9 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
             break;
         }
         int chroma_mode = 0;
+        unsigned long long i4flags = 0;  // prev_intra4x4_pred_mode_flag << 3 | rem_intra4x4_pred_mode, 4 bits per block
+        bool left_i4 = false, above_i4 = false;
+        unsigned above_modes = 0;
         if (inter) {
             if (t == 3 || t == 4) {
                 bool badsub = false;
@@ -637,12 +647,18 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
                 }
             }
         } else {
-            if (i4)
+            if (i4) {
                 for (int blk = 0; blk < 16; blk++) {
                     int f = (int)db_bit(b);
                     int rem = f ? 0 : (int)db_bits(b, 3);
-                    p_i4flag[mbi * 16 + blk] = (uint8_t)((f << 3) | rem);
+                    i4flags |= (unsigned long long)((f << 3) | rem) << (4 * blk);
                 }
+                if (lane < 16) p_i4flag[mbi * 16 + lane] = (uint8_t)((i4flags >> (4 * lane)) & 15);
+                // the neighbours' side of getIntra4x4PredMode, before this macroblock takes the place of the one above
+                left_i4 = mbx > 0 && __builtin_amdgcn_readfirstlane((int)row[mbx - 1].i4) != 0;
+                above_i4 = mby > 0 && __builtin_amdgcn_readfirstlane((int)row[mbx].i4) != 0;
+                above_modes = (unsigned)__builtin_amdgcn_readfirstlane((int)i4row[mbx]);
+            }
             chroma_mode = (int)db_ue(b);
             if (chroma_mode > 3) {
                 atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
@@ -729,6 +745,7 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
                 me.cbpL = (uint8_t)cbpL;
                 me.cbpC = (uint8_t)cbpC;
                 me.skip = 0;
+                me.i4 = i4 ? 1 : 0;
             }
         }
         DEC_WSYNC();
@@ -739,23 +756,32 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
             dec_derive_mvs(d, mvs, mbt, cur, t, mvd, sub);
         } else if (i4) {
             // getIntra4x4PredMode, F/intra.cpp:77-136
+            unsigned long long cm = 0;  // this macroblock's modes, 4 bits per block
             for (int blk = 0; blk < 16; blk++) {
                 bool edgeA = blk == 0 || blk == 2 || blk == 8 || blk == 10;
                 bool edgeB = blk == 0 || blk == 1 || blk == 4 || blk == 5;
-                bool okA = !(edgeA && cur % d.mbw == 0), okB = !(edgeB && cur < d.mbw);
+                bool okA = !(edgeA && mbx == 0), okB = !(edgeB && mby == 0);
                 int mA = 2, mB = 2;
                 if (okA && okB && !constrained_intra) {
-                    int ma = edgeA ? cur - 1 : cur, mb2 = edgeB ? cur - d.mbw : cur;
-                    int ta = mbt[ma], tb = mbt[mb2];
-                    bool a4 = stype == 2 ? ta == 0 : ta == 5, b4 = stype == 2 ? tb == 0 : tb == 5;
-                    mA = a4 ? p_i4mode[((size_t)s * d.nmb + ma) * 16 + c_nbA[blk]] : 2;
-                    mB = b4 ? p_i4mode[((size_t)s * d.nmb + mb2) * 16 + c_nbB[blk]] : 2;
+                    // c_nbA / c_nbB (the neighbouring block to the left / above), 4 bits per block: no table load in the chain
+                    const int nA = (int)((0xebc9af8d63412705ull >> (4 * blk)) & 15), nB = (int)((0xdc76983254fe10baull >> (4 * blk)) & 15);
+                    if (edgeA)
+                        mA = left_i4 ? (int)((left_modes >> (4 * nA)) & 15) : 2;
+                    else
+                        mA = (int)((cm >> (4 * nA)) & 15);
+                    if (edgeB)
+                        mB = above_i4 ? (int)((above_modes >> (4 * ((nB & 1) | ((nB >> 1) & 2)))) & 15) : 2;  // 10, 11, 14, 15 -> 0 .. 3
+                    else
+                        mB = (int)((cm >> (4 * nB)) & 15);
                 }
                 int pm = mA <= mB ? mA : mB;
-                int f = p_i4flag[mbi * 16 + blk];
+                int f = (int)((i4flags >> (4 * blk)) & 15);
                 int mode = (f & 8) ? pm : ((f & 7) < pm ? (f & 7) : (f & 7) + 1);
-                p_i4mode[mbi * 16 + blk] = (uint8_t)mode;
+                cm |= (unsigned long long)mode << (4 * blk);
             }
+            if (lane < 16) p_i4mode[mbi * 16 + lane] = (uint8_t)((cm >> (4 * lane)) & 15);
+            if (lane == 0) i4row[mbx] = (uint16_t)(((cm >> 40) & 0xff) | (((cm >> 56) & 0xff) << 8));  // blocks 10, 11 | 14, 15
+            left_modes = cm;
         }
         more = db_more(b);
         cur++;
@@ -1033,10 +1059,10 @@ void fer_launch_decode_parse(const FerDev &d, const DecBatch &B, hipStream_t st)
         hipLaunchKernelGGL(k_dec_split_luts, dim3(4), dim3(256), 0, st, g_dec_luts);
     }
     // static LDS of k_dec_parse<PW>: the tables + PW * (tcur 24 + stream ring 512 + ChromaACLevel 256 + the macroblock's levels); dynamic: the rows
-    const size_t fixed = sizeof(DecLutsLds), per_wave = 24 + 512 + 256 + FER_LEVELS * 2 + (size_t)d.mbw * sizeof(DecNb);
+    const size_t fixed = sizeof(DecLutsLds), per_wave = 24 + 512 + 256 + FER_LEVELS * 2 + (size_t)d.mbw * (sizeof(DecNb) + 2);
     const int npic = d.S * B.TW;
 #define DEC_PARSE_LAUNCH(PW)                                                                                                          \
-    hipLaunchKernelGGL(k_dec_parse<PW>, dim3((npic + PW - 1) / PW), dim3(64 * PW), (size_t)PW * d.mbw * sizeof(DecNb), st, d, B, \
+    hipLaunchKernelGGL(k_dec_parse<PW>, dim3((npic + PW - 1) / PW), dim3(64 * PW), (size_t)PW * d.mbw * (sizeof(DecNb) + 2), st, d, B, \
                        g_dec_luts)
     const size_t lds = 160 * 1024 - 512;
     hipMemsetAsync(B.state + 2, 0, sizeof(int), st);

@@ -3,7 +3,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pd
 rm -rf $O && mkdir -p $O
-rocprofv3 --kernel-trace --pmc $1 --output-format csv -d $O/a -- python3 tools/dec_rate.py > $O/a.log 2>&1
+rocprofv3 --kernel-trace --pmc $1 --output-format csv -d $O/a -- python3 tools/dec_rate.py $2 > $O/a.log 2>&1
 f=$(find $O/a -name '*counter_collection.csv' | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections
