@@ -191,8 +191,9 @@ int ferhip_set_reference(ferhip_ctx *c, const void *src);
  * GPU path does not implement (I_PCM, CABAC, High profiles, field coding, slice groups) returns FERHIP_E_UNSUP. */
 int ferhip_decode_streams(const uint8_t *const *streams, const size_t *lens, int nstreams, uint8_t *out,
                           int max_pictures, int *pictures, int *width, int *height);
-/* frees the window buffers ferhip_decode_streams keeps between calls (tens of GB for large batches); FERHIP_E_STATE
- * while a decode is running */
+/* frees the window buffers ferhip_decode_streams keeps between calls (tens of GB of HBM for large batches) and the
+ * calling thread's host copy of the streams' RBSP (as large as the streams of its last call); FERHIP_E_STATE while a
+ * decode is running */
 int ferhip_decode_release(void);
 
 /* ---- streaming decoder: RBSP_decode(NALunit) of F/rbsp_decoding.cpp:17 for one stream, NAL unit by NAL unit ----
