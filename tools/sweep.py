@@ -12,7 +12,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 bad = 0
 for it in range(N):
-    W, H = rng.choice([(176, 144), (352, 288), (64, 48), (128, 96), (320, 240), (16, 32), (48, 16)])
+    W, H = rng.choice([(176, 144), (352, 288), (64, 48), (128, 96), (320, 240), (16, 32), (48, 16),
+                       (16, 2064), (32, 4112), (1024, 16), (640, 32), (16, 528)])  # tall / wide: the tile shapes of the first radix pass
     cfg = dict(qp=rng.choice([10, 12, 16, 20, 24, 28, 30]), window=rng.choice([16, 32, 32, 32, 48]),
                maxdiff=rng.choice([3, 3, -1, 0, 6]), intra_every=rng.choice([30, 30, 3, 2]))
     T, S = rng.choice([3, 4, 5]), rng.choice([1, 2, 3, 3, 17, 19])   # >= 16 streams: the eight ticket queues of the motion chain
