@@ -614,11 +614,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(FerDev d, const uint8
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const bool ok = w0 + r * 64 + lane < n;
-        unsigned long long peers = __ballot(ok);  // lanes with the same digit
+        // lanes with the same digit: those whose ballot of every digit bit agrees with this lane's bit
+        // (differences OR-ed per 32-bit half: a v_xor per bit and half, a three-input OR per two bits)
+        unsigned long long peers;
+        {
+            uint32_t dlo = 0, dhi = 0;
 #pragma unroll
-        for (int b = 0; b < RS_BITS; b++) {
-            unsigned long long bal = __ballot((dg[r] >> b) & 1);
-            peers &= ((dg[r] >> b) & 1) ? bal : ~bal;
+            for (int b = 0; b < RS_BITS; b++) {
+                const unsigned long long bal = __ballot((dg[r] >> b) & 1);
+                const uint32_t mine = 0u - ((dg[r] >> b) & 1u);
+                dlo |= (uint32_t)bal ^ mine;
+                dhi |= (uint32_t)(bal >> 32) ^ mine;
+            }
+            peers = __ballot(ok) & ~(((unsigned long long)dhi << 32) | dlo);
         }
         const unsigned before = run[wv][dg[r]];
         rk[r] = before + (unsigned)__popcll(peers & lt);
