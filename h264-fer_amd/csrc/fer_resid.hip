@@ -28,14 +28,17 @@
 #ifndef RESID_WAVES
 #define RESID_WAVES 6  // 74 registers, no scratch; the kernel is a chain of memory round trips and gains from the sixth wavefront
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RESID_WAVES, 8))) void k_p_resid(FerDev d)
+#ifndef RES_MBW
+#define RES_MBW 4  // macroblocks (wavefronts) of a workgroup, side by side
+#endif
+__global__ __launch_bounds__(64 * RES_MBW) __attribute__((amdgpu_waves_per_eu(RESID_WAVES, 8))) void k_p_resid(FerDev d)
 {
-    __shared__ __align__(16) int16_t lvs_[4][FER_LEVELS];
-    __shared__ __align__(4) uint8_t tcs_[4][24];
+    __shared__ __align__(16) int16_t lvs_[RES_MBW][FER_LEVELS];
+    __shared__ __align__(4) uint8_t tcs_[RES_MBW][24];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int16_t *lvs = lvs_[wv];
     uint8_t *tcs = tcs_[wv];
-    const int s = blockIdx.y, mb = (int)xcd_swizzle(blockIdx.x, gridDim.x) * 4 + wv;
+    const int s = blockIdx.y, mb = (int)xcd_swizzle(blockIdx.x, gridDim.x) * RES_MBW + wv;
     if (mb >= d.nmb) return;
     const int W = d.W, H = d.H, Wc = d.Wc, Hc = d.Hc;
     int *mbt = d.mb_type + (size_t)s * d.nmb;
@@ -251,5 +254,5 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RESID_WAVES
 
 void fer_launch_p_resid(const FerDev &d, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_p_resid, dim3((d.nmb + 3) / 4, d.S), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_p_resid, dim3((d.nmb + RES_MBW - 1) / RES_MBW, d.S), dim3(64 * RES_MBW), 0, st, d);
 }
