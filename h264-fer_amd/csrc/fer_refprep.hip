@@ -22,6 +22,7 @@
 #define IT_W 128
 #define IT_H 8
 #endif
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
 #define IT_PITCH (IT_W + 8)  // bytes of a tile row: IT_W + 5 apron columns, rounded up to dwords
 __global__ __launch_bounds__(256) void k_interp(FerDev d)
 {
@@ -52,41 +53,58 @@ __global__ __launch_bounds__(256) void k_interp(FerDev d)
     const int g = tid % (IT_W / 4), ty = tid / (IT_W / 4);
     const int x = x0 + g * 4, y = y0 + ty;
     if (x >= W || y >= H) return;
-    // rows y-2 .. y+3, columns x-2 .. x+6 (tv[r][k] = sample (x - 2 + k, y - 2 + r))
-    int tv[6][9];
+    // Rows y-2 .. y+3, columns x-2 .. x+9 of the tile as three dwords per row.  The six-tap filters run on PAIRS of
+    // neighbouring samples (two 16-bit lanes per register, v_pk_*: every intermediate fits 16 bits), the twelve averaged
+    // planes on four samples packed in a dword ((a | b) - (((a ^ b) >> 1) & 0x7f7f7f7f) = (a + b + 1) >> 1 per byte).
+    uint32_t w[6][3];
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-        const uint32_t *w = (const uint32_t *)&tile[ty + r][g * 4];
-        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            tv[r][k] = (w0 >> (8 * k)) & 0xff;
-            tv[r][4 + k] = (w1 >> (8 * k)) & 0xff;
-        }
-        tv[r][8] = w2 & 0xff;
+        const uint32_t *q = (const uint32_t *)&tile[ty + r][g * 4];
+        w[r][0] = q[0];
+        w[r][1] = q[1];
+        w[r][2] = q[2];
     }
-    int V[9];  // vertical half-sample values of the nine columns
+    // pr(r, c) = samples c, c + 1 of row r (c = 0 is column x - 2) as 16-bit lanes
+    auto pr = [&](int r, int c) -> s16x2_t {
+        const uint32_t lo = w[r][c >> 2], hi = w[r][c >> 2 < 2 ? (c >> 2) + 1 : 2];
+        const uint32_t i0 = (uint32_t)(c & 3), i1 = i0 + 1;  // (sample 3 of a dword pairs with byte 0 of the next one)
+        return __builtin_bit_cast(s16x2_t, __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (i1 << 16) | i0));
+    };
+    auto tap6p = [](s16x2_t E, s16x2_t F, s16x2_t G, s16x2_t H, s16x2_t I, s16x2_t J) -> s16x2_t {
+        const s16x2_t c20 = {20, 20}, c5 = {-5, -5}, c16 = {16, 16}, c0 = {0, 0}, c255 = {255, 255};
+        s16x2_t t = (G + H) * c20 + c16;
+        t = (F + I) * c5 + t;
+        t = (t + (E + J)) >> 5;
+        return __builtin_elementwise_min(__builtin_elementwise_max(t, c0), c255);
+    };
+    auto pack4 = [](s16x2_t a, s16x2_t b2) -> uint32_t {  // four clipped samples -> bytes
+        return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b2), __builtin_bit_cast(uint32_t, a), 0x06040200u);
+    };
+    auto mid4 = [](uint32_t a, uint32_t b2) -> uint32_t { return (a | b2) - (((a ^ b2) >> 1) & 0x7f7f7f7fu); };
+    // vertical half samples of columns 0 .. 8 (pairs at the even columns), then the pairs at the odd ones
+    s16x2_t VP[8];
 #pragma unroll
-    for (int k = 0; k < 9; k++) V[k] = tap6(tv[0][k], tv[1][k], tv[2][k], tv[3][k], tv[4][k], tv[5][k]);
-    uint32_t o[16];
-#pragma unroll
-    for (int f = 0; f < 16; f++) o[f] = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int G = tv[2][k + 2];
-        const int b = tap6(tv[2][k], tv[2][k + 1], G, tv[2][k + 3], tv[2][k + 4], tv[2][k + 5]);
-        const int sS = tap6(tv[3][k], tv[3][k + 1], tv[3][k + 2], tv[3][k + 3], tv[3][k + 4], tv[3][k + 5]);
-        const int h = V[k + 2], m = V[k + 3];
-        const int j = tap6(V[k], V[k + 1], h, m, V[k + 4], V[k + 5]);
-        const int v[16] = {G,          FER_MID(G, b), b,  FER_MID(b, tv[2][k + 3]), FER_MID(G, h),           FER_MID(b, h),
-                           FER_MID(b, j), FER_MID(b, m), h,  FER_MID(h, j),            j,                       FER_MID(j, m),
-                           FER_MID(h, tv[3][k + 2]), FER_MID(h, sS), FER_MID(j, sS),   FER_MID(sS, m)};
-#pragma unroll
-        for (int f = 0; f < 16; f++) o[f] |= (uint32_t)v[f] << (8 * k);
+    for (int c = 0; c < 10; c += 2) {
+        const s16x2_t v = tap6p(pr(0, c), pr(1, c), pr(2, c), pr(3, c), pr(4, c), pr(5, c));
+        if (c < 8) VP[c] = v;
+        if (c >= 2)  // (V[c-1], V[c]) from (V[c-2], V[c-1]) and (V[c], V[c+1])
+            VP[c - 1] = __builtin_bit_cast(s16x2_t, __builtin_amdgcn_alignbit(__builtin_bit_cast(uint32_t, v), __builtin_bit_cast(uint32_t, VP[c - 2]), 16));
     }
+    const uint32_t G4 = __builtin_amdgcn_alignbyte(w[2][1], w[2][0], 2);   // the samples themselves
+    const uint32_t Gn4 = __builtin_amdgcn_alignbyte(w[2][1], w[2][0], 3);  // ... one column on
+    const uint32_t Gd4 = __builtin_amdgcn_alignbyte(w[3][1], w[3][0], 2);  // ... one row on
+    const uint32_t b4 = pack4(tap6p(pr(2, 0), pr(2, 1), pr(2, 2), pr(2, 3), pr(2, 4), pr(2, 5)),
+                              tap6p(pr(2, 2), pr(2, 3), pr(2, 4), pr(2, 5), pr(2, 6), pr(2, 7)));
+    const uint32_t s4 = pack4(tap6p(pr(3, 0), pr(3, 1), pr(3, 2), pr(3, 3), pr(3, 4), pr(3, 5)),
+                              tap6p(pr(3, 2), pr(3, 3), pr(3, 4), pr(3, 5), pr(3, 6), pr(3, 7)));
+    const uint32_t h4 = pack4(VP[2], VP[4]), m4 = pack4(VP[3], VP[5]);
+    // the centre sample filters the CLIPPED vertical values (F/mocomp.cpp:71)
+    const uint32_t j4 = pack4(tap6p(VP[0], VP[1], VP[2], VP[3], VP[4], VP[5]), tap6p(VP[2], VP[3], VP[4], VP[5], VP[6], VP[7]));
+    const uint32_t o[16] = {G4,           mid4(G4, b4), b4,           mid4(b4, Gn4), mid4(G4, h4), mid4(b4, h4), mid4(b4, j4), mid4(b4, m4),
+                            h4,           mid4(h4, j4), j4,           mid4(j4, m4),  mid4(h4, Gd4), mid4(h4, s4), mid4(j4, s4), mid4(s4, m4)};
     const size_t off = (size_t)y * d.ipitch + x;
 #pragma unroll
-    for (int f = 0; f < 16; f++) *(uint32_t *)(P + (size_t)f * d.iplane + off) = o[f];
+    for (int f = 0; f < 16; f++) *(uint32_t *)(P + (size_t)f * d.iplane + off) = o[f];  // (streaming stores: 6.1 ms against 3.1)
 }
 
 // right and bottom margins of the 16 planes: pixel (x, y) beyond the picture = the plane's (min(x, W-1), min(y, H-1))
