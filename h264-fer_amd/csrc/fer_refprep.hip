@@ -36,18 +36,27 @@ __global__ __launch_bounds__(256) void k_interp(FerDev d)
     const int t = (int)xcd_swizzle(blockIdx.x, gridDim.x);
     const int x0 = (t % tw) * IT_W, y0 = (t / tw) * IT_H;
     const int tid = threadIdx.x;
-    for (int i = tid; i < (IT_H + 5) * (IT_PITCH / 4); i += 256) {
-        const int r = i / (IT_PITCH / 4), c4 = (i % (IT_PITCH / 4)) * 4;
-        const int y = iclamp(y0 + r - 2, 0, H - 1), xs = x0 + c4 - 2;  // tile byte c4 = picture column xs
-        uint32_t v;
-        if (xs >= 0 && xs + 3 < W) {
-            v = load_u8x4(R + (size_t)y * W + xs);
-        } else {
-            v = 0;
+    {  // the tile: every load of the thread is requested before the first one is waited for
+        constexpr int NL = ((IT_H + 5) * (IT_PITCH / 4) + 255) / 256;
+        uint32_t v[NL];
 #pragma unroll
-            for (int k = 0; k < 4; k++) v |= (uint32_t)R[(size_t)y * W + iclamp(xs + k, 0, W - 1)] << (8 * k);
+        for (int k = 0; k < NL; k++) {
+            const int i = min(tid + k * 256, (IT_H + 5) * (IT_PITCH / 4) - 1);
+            const int r = i / (IT_PITCH / 4), c4 = (i % (IT_PITCH / 4)) * 4;
+            const int y = iclamp(y0 + r - 2, 0, H - 1), xs = x0 + c4 - 2;  // tile byte c4 = picture column xs
+            if (xs >= 0 && xs + 3 < W) {
+                v[k] = load_u8x4(R + (size_t)y * W + xs);
+            } else {
+                v[k] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) v[k] |= (uint32_t)R[(size_t)y * W + iclamp(xs + b, 0, W - 1)] << (8 * b);
+            }
         }
-        *(uint32_t *)&tile[r][c4] = v;
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int i = tid + k * 256;
+            if (i < (IT_H + 5) * (IT_PITCH / 4)) *(uint32_t *)&tile[i / (IT_PITCH / 4)][(i % (IT_PITCH / 4)) * 4] = v[k];
+        }
     }
     __syncthreads();
     const int g = tid % (IT_W / 4), ty = tid / (IT_W / 4);
