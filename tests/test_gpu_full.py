@@ -404,6 +404,31 @@ def test_gpu_decoder_1080p(pkg, fo):
     assert np.array_equal(out[:, 0], rec[:, 0])  # decoder output == encoder reconstruction
 
 
+def test_gpu_decoder_survives_damaged_slice_data(pkg, fo):
+    """Bytes of the slice data overwritten at random: the parse either reaches the end of the picture or reports a syntax /
+    unsupported error through the return code -- it never hangs or leaves the library unusable (every loop of k_dec_parse is
+    bounded by the picture or the block, every table index by construction) -- and the undamaged stream still decodes bit-exactly
+    right after."""
+    clean = (GOLD / "qcif_ippp_4f_qp12_w16.264").read_bytes()
+    ref = _oracle_decode(fo, clean)
+    rng = np.random.default_rng(5)
+    outcomes = {"ok": 0, "error": 0}
+    for trial in range(24):
+        bad = bytearray(clean)
+        lo = 64 + int(rng.integers(0, len(bad) - 200))  # behind the parameter sets and the first slice header
+        for k in range(int(rng.integers(1, 6))):
+            bad[min(lo + int(rng.integers(0, 64)), len(bad) - 1)] = int(rng.integers(1, 256))  # (no new start codes: never 0)
+        try:
+            out, pics, w, h = pkg.decode_streams([bytes(bad), clean], ref.shape[0])
+            outcomes["ok"] += 1
+            assert np.array_equal(out[:, 1], ref)  # the damaged neighbour does not disturb the other stream of the batch
+        except pkg.FerHipError:
+            outcomes["error"] += 1
+    out, pics, w, h = pkg.decode_streams([clean], ref.shape[0])
+    assert pics == [ref.shape[0]] and np.array_equal(out[:, 0], ref)
+    assert outcomes["ok"] + outcomes["error"] == 24
+
+
 @pytest.mark.parametrize("W,H,S", [(3840, 64, 3), (6400, 32, 2), (12800, 16, 1)])
 def test_gpu_decoder_wide_pictures(pkg, fo, W, H, S):
     """The parse kernel keeps a row of neighbour context per picture in LDS and is instantiated for 16, 8, 4 or 1 pictures
