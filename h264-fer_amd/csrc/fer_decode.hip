@@ -504,306 +504,306 @@ __global__ __launch_bounds__(64 * DEC_PW) void k_dec_parse(FerDev d, DecBatch B,
     // workgroup in turn (so to different CUs), and a wavefront that has finished a short P picture takes the next one
     // instead of idling beside an I picture until the workgroup ends.
     for (;;) {
-    size_t pic;
-    {
-        int tk = 0;
-        if (lane == 0) tk = atomicAdd(&B.state[2], 1);
-        tk = __builtin_amdgcn_readfirstlane(tk);
-        if (tk >= (int)gridDim.x * DEC_PW) break;
-        pic = (size_t)(tk % DEC_PW) * gridDim.x + (size_t)(tk / DEC_PW);  // ticket -> picture: DEC_PW consecutive tickets are gridDim.x pictures apart
-    }
-    if (pic >= (size_t)B.TW * d.S) continue;
-    const int tpic = (int)(pic / d.S), s = (int)(pic % d.S);
-    const uint32_t *info = B.info + pic * 6;
-    // this picture's slice of the side information (the kernel argument d itself is never written: a modified copy of
-    // that 900-byte structure would live in scratch memory)
-    const size_t po = (size_t)tpic * d.S * d.nmb;
-    int *const p_mb_type = B.mb_type + po;
-    short *const p_mv = B.mv + po * 8;
-    uint8_t *const p_cbp = B.cbp + po * 2, *const p_tc = B.tc + po * 24, *const p_i4mode = B.i4mode + po * 16;
-    uint8_t *const p_i4flag = B.i4flag + po * 16, *const p_chroma_mode = B.chroma_mode + po, *const p_dec_qp = B.dec_qp + po;
-    int16_t *const p_levels = B.levels + po * FER_LEVELS;
-    uint8_t *carry = B.carry + pic * d.nmb;
-    int *st = B.state + pic * 4, *summ = B.summ + pic * 4;
-    // the slice parameters are the same in every lane: scalar registers, so that everything derived from them
-    // (bit position, window, QP) stays on the scalar unit
-    const unsigned i_size = (unsigned)__builtin_amdgcn_readfirstlane((int)info[0]);
-    const unsigned i_pos = (unsigned)__builtin_amdgcn_readfirstlane((int)info[1]);
-    const int i_slice = __builtin_amdgcn_readfirstlane((int)info[2]);
-    const int stype = i_slice & 255;
-    // ref_idx_l0 is parsed and dropped (every prediction uses the one stored picture): in sub_mb_pred the reference
-    // reads it when the slice carried num_ref_idx_active_override_flag, in mb_pred when the active count left behind
-    // by the last override is > 1 (F/rbsp_decoding.cpp:156-161, :217-221)
-    const bool ref_sub = ((i_slice >> 8) & 1) != 0, ref_mb = (i_slice >> 16) > 0;
-    const unsigned i_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)info[4]), i_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)info[5]);
-    if (i_size == 0) {  // no picture for this stream at this step
-        if (lane == 0) {
-            st[1] = 0;
-            summ[0] = summ[3] = 0;
+        size_t pic;
+        {
+            int tk = 0;
+            if (lane == 0) tk = atomicAdd(&B.state[2], 1);
+            tk = __builtin_amdgcn_readfirstlane(tk);
+            if (tk >= (int)gridDim.x * DEC_PW) break;
+            pic = (size_t)(tk % DEC_PW) * gridDim.x + (size_t)(tk / DEC_PW);  // ticket -> picture: DEC_PW consecutive tickets are gridDim.x pictures apart
         }
-        continue;
-    }
-    const bool constrained_intra = __builtin_amdgcn_readfirstlane((int)B.hdr[pic * 4 + 1]) != 0;
-    DecBits b;
-    db_open(b, B.rbsp + (((size_t)i_hi << 32) | i_lo), i_size, i_pos, ring_w[wv]);
-    int QPy = __builtin_amdgcn_readfirstlane((int)info[3]);
-    int *mbt = p_mb_type + (size_t)s * d.nmb;
-    short *mvs = p_mv + (size_t)s * d.nmb * 8;
-    int mb_qp_delta = 0;  // the inherited value is added by k_dec_patch
-    bool delta_known = false, cac_known = false;
-    int n_inherit = 0;    // macroblocks whose QP step used the inherited delta
-    for (int i = lane; i < 2 * 4 * 16; i += 64) (&cac[0][0][0])[i] = 0;
-    DEC_WSYNC();
-    int cur = 0;
-    bool more = true;
-    int mvd[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-    int sub[4] = {0, 0, 0, 0};
+        if (pic >= (size_t)B.TW * d.S) continue;
+        const int tpic = (int)(pic / d.S), s = (int)(pic % d.S);
+        const uint32_t *info = B.info + pic * 6;
+        // this picture's slice of the side information (the kernel argument d itself is never written: a modified copy of
+        // that 900-byte structure would live in scratch memory)
+        const size_t po = (size_t)tpic * d.S * d.nmb;
+        int *const p_mb_type = B.mb_type + po;
+        short *const p_mv = B.mv + po * 8;
+        uint8_t *const p_cbp = B.cbp + po * 2, *const p_tc = B.tc + po * 24, *const p_i4mode = B.i4mode + po * 16;
+        uint8_t *const p_i4flag = B.i4flag + po * 16, *const p_chroma_mode = B.chroma_mode + po, *const p_dec_qp = B.dec_qp + po;
+        int16_t *const p_levels = B.levels + po * FER_LEVELS;
+        uint8_t *carry = B.carry + pic * d.nmb;
+        int *st = B.state + pic * 4, *summ = B.summ + pic * 4;
+        // the slice parameters are the same in every lane: scalar registers, so that everything derived from them
+        // (bit position, window, QP) stays on the scalar unit
+        const unsigned i_size = (unsigned)__builtin_amdgcn_readfirstlane((int)info[0]);
+        const unsigned i_pos = (unsigned)__builtin_amdgcn_readfirstlane((int)info[1]);
+        const int i_slice = __builtin_amdgcn_readfirstlane((int)info[2]);
+        const int stype = i_slice & 255;
+        // ref_idx_l0 is parsed and dropped (every prediction uses the one stored picture): in sub_mb_pred the reference
+        // reads it when the slice carried num_ref_idx_active_override_flag, in mb_pred when the active count left behind
+        // by the last override is > 1 (F/rbsp_decoding.cpp:156-161, :217-221)
+        const bool ref_sub = ((i_slice >> 8) & 1) != 0, ref_mb = (i_slice >> 16) > 0;
+        const unsigned i_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)info[4]), i_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)info[5]);
+        if (i_size == 0) {  // no picture for this stream at this step
+            if (lane == 0) {
+                st[1] = 0;
+                summ[0] = summ[3] = 0;
+            }
+            continue;
+        }
+        const bool constrained_intra = __builtin_amdgcn_readfirstlane((int)B.hdr[pic * 4 + 1]) != 0;
+        DecBits b;
+        db_open(b, B.rbsp + (((size_t)i_hi << 32) | i_lo), i_size, i_pos, ring_w[wv]);
+        int QPy = __builtin_amdgcn_readfirstlane((int)info[3]);
+        int *mbt = p_mb_type + (size_t)s * d.nmb;
+        short *mvs = p_mv + (size_t)s * d.nmb * 8;
+        int mb_qp_delta = 0;  // the inherited value is added by k_dec_patch
+        bool delta_known = false, cac_known = false;
+        int n_inherit = 0;    // macroblocks whose QP step used the inherited delta
+        for (int i = lane; i < 2 * 4 * 16; i += 64) (&cac[0][0][0])[i] = 0;
+        DEC_WSYNC();
+        int cur = 0;
+        bool more = true;
+        int mvd[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        int sub[4] = {0, 0, 0, 0};
 #ifdef FER_PROBE
-    long long tacc[4] = {0, 0, 0, 0}, tmark = wall_clock64();
+        long long tacc[4] = {0, 0, 0, 0}, tmark = wall_clock64();
 #define DP_MARK(k)                        \
-    {                                     \
-        long long now_ = wall_clock64();  \
-        tacc[k] += now_ - tmark;          \
-        tmark = now_;                     \
-    }
+        {                                     \
+            long long now_ = wall_clock64();  \
+            tacc[k] += now_ - tmark;          \
+            tmark = now_;                     \
+        }
 #else
 #define DP_MARK(k)
 #endif
-    while (more && cur < d.nmb) {
-        DP_MARK(3)
-        if (stype != 2) {
-            int run = (int)db_ue(b);
-            for (int i = 0; i < run && cur < d.nmb; i++) {
-                size_t mbi = (size_t)s * d.nmb + cur;
-                mbt[cur] = FER_P_SKIP;
-                if (lane == 0) {
-                    row[cur % d.mbw].skip = 1;
-                    row[cur % d.mbw].i4 = 0;
+        while (more && cur < d.nmb) {
+            DP_MARK(3)
+            if (stype != 2) {
+                int run = (int)db_ue(b);
+                for (int i = 0; i < run && cur < d.nmb; i++) {
+                    size_t mbi = (size_t)s * d.nmb + cur;
+                    mbt[cur] = FER_P_SKIP;
+                    if (lane == 0) {
+                        row[cur % d.mbw].skip = 1;
+                        row[cur % d.mbw].i4 = 0;
+                    }
+                    for (int k = 0; k < 4; k++) mvd[k][0] = mvd[k][1] = 0;  // ClearMVD in PredictMV
+                    dec_derive_mvs(d, mvs, mbt, cur, FER_P_SKIP, mvd, sub);
+                    QPy = (QPy + mb_qp_delta + 52) % 52;
+                    n_inherit += delta_known ? 0 : 1;
+                    p_dec_qp[mbi] = (uint8_t)QPy;
+                    if (lane == 0) carry[cur] = 0;
+                    cur++;
                 }
-                for (int k = 0; k < 4; k++) mvd[k][0] = mvd[k][1] = 0;  // ClearMVD in PredictMV
-                dec_derive_mvs(d, mvs, mbt, cur, FER_P_SKIP, mvd, sub);
-                QPy = (QPy + mb_qp_delta + 52) % 52;
-                n_inherit += delta_known ? 0 : 1;
-                p_dec_qp[mbi] = (uint8_t)QPy;
-                if (lane == 0) carry[cur] = 0;
-                cur++;
+                if (cur != 0 || run > 0) more = db_more(b);
             }
-            if (cur != 0 || run > 0) more = db_more(b);
-        }
-        if (!(more && cur < d.nmb)) break;
-        const size_t mbi = (size_t)s * d.nmb + cur;
-        const int mbx = cur % d.mbw, mby = cur / d.mbw;
-        int16_t *lv = mblv;
-        for (int i = lane; i < FER_LEVELS / 2; i += 64) ((uint32_t *)mblv)[i] = 0;
-        int t = (int)db_ue(b);
-        if (t > 31 || (stype == 2 && t > 24)) {
-            atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
-            break;
-        }
-        mbt[cur] = t;
-        const int k = stype == 2 ? t : t - 5;  // index into the I macroblock table
-        const bool i4 = stype == 2 ? t == 0 : t == 5;
-        const bool i16 = stype == 2 ? (t >= 1 && t <= 24) : (t >= 6 && t <= 29);
-        const bool inter = !i4 && !i16;
-        if ((t == 25 && stype == 2) || (t == 30 && stype != 2)) {
-            atomicOr(&d.status[s], FER_ERR_DEC_UNSUPPORTED);  // I_PCM
-            break;
-        }
-        int chroma_mode = 0;
-        unsigned long long i4flags = 0;  // prev_intra4x4_pred_mode_flag << 3 | rem_intra4x4_pred_mode, 4 bits per block
-        bool left_i4 = false, above_i4 = false;
-        unsigned above_modes = 0;
-        if (inter) {
-            if (t == 3 || t == 4) {
-                bool badsub = false;
-                for (int i = 0; i < 4; i++) {
-                    sub[i] = (int)db_ue(b);
-                    badsub |= sub[i] > 3;
-                }
-                if (badsub) {
-                    atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
-                    break;
-                }
-                if (ref_sub && t != FER_P_8x8ref0)
-                    for (int i = 0; i < 4; i++) db_te(b);
-                for (int i = 0; i < 4; i++) {
-                    // sub-partitions: 8x8 1, 8x4 2, 4x8 2, 4x4 4 vector differences, of which DeriveMVs keeps the first
-                    const int nsub = sub[i] == 0 ? 1 : (sub[i] == 3 ? 4 : 2);
-                    for (int j = 0; j < nsub; j++) {
-                        int dx = db_se(b), dy = db_se(b);
-                        if (j == 0) {
-                            mvd[i][0] = dx;
-                            mvd[i][1] = dy;
+            if (!(more && cur < d.nmb)) break;
+            const size_t mbi = (size_t)s * d.nmb + cur;
+            const int mbx = cur % d.mbw, mby = cur / d.mbw;
+            int16_t *lv = mblv;
+            for (int i = lane; i < FER_LEVELS / 2; i += 64) ((uint32_t *)mblv)[i] = 0;
+            int t = (int)db_ue(b);
+            if (t > 31 || (stype == 2 && t > 24)) {
+                atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
+                break;
+            }
+            mbt[cur] = t;
+            const int k = stype == 2 ? t : t - 5;  // index into the I macroblock table
+            const bool i4 = stype == 2 ? t == 0 : t == 5;
+            const bool i16 = stype == 2 ? (t >= 1 && t <= 24) : (t >= 6 && t <= 29);
+            const bool inter = !i4 && !i16;
+            if ((t == 25 && stype == 2) || (t == 30 && stype != 2)) {
+                atomicOr(&d.status[s], FER_ERR_DEC_UNSUPPORTED);  // I_PCM
+                break;
+            }
+            int chroma_mode = 0;
+            unsigned long long i4flags = 0;  // prev_intra4x4_pred_mode_flag << 3 | rem_intra4x4_pred_mode, 4 bits per block
+            bool left_i4 = false, above_i4 = false;
+            unsigned above_modes = 0;
+            if (inter) {
+                if (t == 3 || t == 4) {
+                    bool badsub = false;
+                    for (int i = 0; i < 4; i++) {
+                        sub[i] = (int)db_ue(b);
+                        badsub |= sub[i] > 3;
+                    }
+                    if (badsub) {
+                        atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
+                        break;
+                    }
+                    if (ref_sub && t != FER_P_8x8ref0)
+                        for (int i = 0; i < 4; i++) db_te(b);
+                    for (int i = 0; i < 4; i++) {
+                        // sub-partitions: 8x8 1, 8x4 2, 4x8 2, 4x4 4 vector differences, of which DeriveMVs keeps the first
+                        const int nsub = sub[i] == 0 ? 1 : (sub[i] == 3 ? 4 : 2);
+                        for (int j = 0; j < nsub; j++) {
+                            int dx = db_se(b), dy = db_se(b);
+                            if (j == 0) {
+                                mvd[i][0] = dx;
+                                mvd[i][1] = dy;
+                            }
                         }
+                    }
+                } else {
+                    int np = t == 0 ? 1 : 2;
+                    if (ref_mb)
+                        for (int i = 0; i < np; i++) db_te(b);
+                    for (int i = 0; i < np; i++) {
+                        mvd[i][0] = db_se(b);
+                        mvd[i][1] = db_se(b);
                     }
                 }
             } else {
-                int np = t == 0 ? 1 : 2;
-                if (ref_mb)
-                    for (int i = 0; i < np; i++) db_te(b);
-                for (int i = 0; i < np; i++) {
-                    mvd[i][0] = db_se(b);
-                    mvd[i][1] = db_se(b);
+                if (i4) {
+                    for (int blk = 0; blk < 16; blk++) {
+                        int f = (int)db_bit(b);
+                        int rem = f ? 0 : (int)db_bits(b, 3);
+                        i4flags |= (unsigned long long)((f << 3) | rem) << (4 * blk);
+                    }
+                    if (lane < 16) p_i4flag[mbi * 16 + lane] = (uint8_t)((i4flags >> (4 * lane)) & 15);
+                    // the neighbours' side of getIntra4x4PredMode, before this macroblock takes the place of the one above
+                    left_i4 = mbx > 0 && __builtin_amdgcn_readfirstlane((int)row[mbx - 1].i4) != 0;
+                    above_i4 = mby > 0 && __builtin_amdgcn_readfirstlane((int)row[mbx].i4) != 0;
+                    above_modes = (unsigned)__builtin_amdgcn_readfirstlane((int)i4row[mbx]);
+                }
+                chroma_mode = (int)db_ue(b);
+                if (chroma_mode > 3) {
+                    atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
+                    break;
                 }
             }
-        } else {
-            if (i4) {
+            int cbpL, cbpC;
+            if (!i16) {
+                unsigned code = db_ue(b);
+                if (code > 47) {
+                    atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
+                    break;
+                }
+                int cbp = i4 ? c_code_cbp_intra[code] : c_code_cbp_inter[code];
+                cbpL = cbp & 15;
+                cbpC = cbp >> 4;
+            } else {
+                cbpC = ((k - 1) / 4) % 3;
+                cbpL = k >= 13 ? 15 : 0;
+            }
+            p_cbp[mbi * 2] = (uint8_t)cbpL;
+            p_cbp[mbi * 2 + 1] = (uint8_t)cbpC;
+            p_chroma_mode[mbi] = (uint8_t)chroma_mode;
+            for (int i = lane; i < 24; i += 64) tcur[i] = 0;
+            DEC_WSYNC();
+            DP_MARK(0)
+            bool bad = false;
+            if (cbpL > 0 || cbpC > 0 || i16) {
+                mb_qp_delta = db_se(b);
+                delta_known = true;
+                if (mb_qp_delta < -26 || mb_qp_delta > 25) bad = true;
+                // residual(0,15), F/residual.cpp:959-1067
+                if (i16 && !bad) {
+                    int n = dec_block(b, &lut, lv + FER_LV_DC16, 16, dec_nC(row, mbx, mby, true, 0, 0, tcur, cbpL, cbpC));
+                    bad |= n < 0;
+                    if (n >= 0) tcur[0] = (uint8_t)n;
+                    DEC_WSYNC();
+                }
+                for (int i8 = 0; i8 < 4 && !bad; i8++)
+                    if (cbpL & (1 << i8))
+                        for (int i4x = 0; i4x < 4 && !bad; i4x++) {
+                            int blk = i8 * 4 + i4x;
+                            int n = dec_block(b, &lut, lv + blk * 16, i16 ? 15 : 16, dec_nC(row, mbx, mby, true, blk, 0, tcur, cbpL, cbpC));
+                            bad |= n < 0;
+                            if (n >= 0) tcur[blk] = (uint8_t)n;
+                            DEC_WSYNC();
+                        }
+                for (int pl = 0; pl < 2 && !bad; pl++)
+                    if (cbpC & 3) bad |= dec_block(b, &lut, lv + FER_LV_CDC + pl * 4, 4, -1) < 0;
+                for (int pl = 0; pl < 2 && !bad; pl++)
+                    for (int cb = 0; cb < 4 && !bad; cb++) {
+                        if (cbpC & 2) {
+                            for (int i = lane; i < 16; i += 64) cac[pl][cb][i] = 0;
+                            DEC_WSYNC();
+                            int n = dec_block(b, &lut, &cac[pl][cb][0], 15, dec_nC(row, mbx, mby, false, cb, pl, tcur, cbpL, cbpC));
+                            bad |= n < 0;
+                            if (n >= 0) tcur[16 + pl * 4 + cb] = (uint8_t)n;
+                            DEC_WSYNC();
+                        } else {
+                            for (int i = lane; i < 16; i += 64) cac[pl][cb][i] = 0;
+                            DEC_WSYNC();
+                        }
+                    }
+            }
+            DP_MARK(1)
+            if (bad) {
+                atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
+                break;
+            }
+            // chroma AC of this macroblock = the persistent ChromaACLevel (stale when cbp == 0)
+            if (cbpL > 0 || cbpC > 0 || i16) cac_known = true;  // every block was parsed or cleared above
+            if (lane == 0) carry[cur] = cac_known ? 0 : 1;
+            for (int i = lane; i < 120; i += 64) lv[FER_LV_CAC + i] = cac[i / 60][(i % 60) / 15][i % 15];
+            DEC_WSYNC();
+            {  // the finished macroblock: levels to memory (one coalesced pass), counts into the neighbour row
+                uint32_t *g = (uint32_t *)(p_levels + mbi * FER_LEVELS);
+                for (int i = lane; i < FER_LEVELS / 2; i += 64) g[i] = ((const uint32_t *)mblv)[i];
+                DecNb &me = row[mbx];
+                if (lane < 24) {
+                    p_tc[mbi * 24 + lane] = tcur[lane];
+                    me.tc[lane] = tcur[lane];
+                }
+                if (lane == 0) {
+                    me.cbpL = (uint8_t)cbpL;
+                    me.cbpC = (uint8_t)cbpC;
+                    me.skip = 0;
+                    me.i4 = i4 ? 1 : 0;
+                }
+            }
+            DEC_WSYNC();
+            QPy = (QPy + mb_qp_delta + 52) % 52;
+            n_inherit += delta_known ? 0 : 1;
+            p_dec_qp[mbi] = (uint8_t)QPy;
+            if (inter) {
+                dec_derive_mvs(d, mvs, mbt, cur, t, mvd, sub);
+            } else if (i4) {
+                // getIntra4x4PredMode, F/intra.cpp:77-136
+                unsigned long long cm = 0;  // this macroblock's modes, 4 bits per block
                 for (int blk = 0; blk < 16; blk++) {
-                    int f = (int)db_bit(b);
-                    int rem = f ? 0 : (int)db_bits(b, 3);
-                    i4flags |= (unsigned long long)((f << 3) | rem) << (4 * blk);
-                }
-                if (lane < 16) p_i4flag[mbi * 16 + lane] = (uint8_t)((i4flags >> (4 * lane)) & 15);
-                // the neighbours' side of getIntra4x4PredMode, before this macroblock takes the place of the one above
-                left_i4 = mbx > 0 && __builtin_amdgcn_readfirstlane((int)row[mbx - 1].i4) != 0;
-                above_i4 = mby > 0 && __builtin_amdgcn_readfirstlane((int)row[mbx].i4) != 0;
-                above_modes = (unsigned)__builtin_amdgcn_readfirstlane((int)i4row[mbx]);
-            }
-            chroma_mode = (int)db_ue(b);
-            if (chroma_mode > 3) {
-                atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
-                break;
-            }
-        }
-        int cbpL, cbpC;
-        if (!i16) {
-            unsigned code = db_ue(b);
-            if (code > 47) {
-                atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
-                break;
-            }
-            int cbp = i4 ? c_code_cbp_intra[code] : c_code_cbp_inter[code];
-            cbpL = cbp & 15;
-            cbpC = cbp >> 4;
-        } else {
-            cbpC = ((k - 1) / 4) % 3;
-            cbpL = k >= 13 ? 15 : 0;
-        }
-        p_cbp[mbi * 2] = (uint8_t)cbpL;
-        p_cbp[mbi * 2 + 1] = (uint8_t)cbpC;
-        p_chroma_mode[mbi] = (uint8_t)chroma_mode;
-        for (int i = lane; i < 24; i += 64) tcur[i] = 0;
-        DEC_WSYNC();
-        DP_MARK(0)
-        bool bad = false;
-        if (cbpL > 0 || cbpC > 0 || i16) {
-            mb_qp_delta = db_se(b);
-            delta_known = true;
-            if (mb_qp_delta < -26 || mb_qp_delta > 25) bad = true;
-            // residual(0,15), F/residual.cpp:959-1067
-            if (i16 && !bad) {
-                int n = dec_block(b, &lut, lv + FER_LV_DC16, 16, dec_nC(row, mbx, mby, true, 0, 0, tcur, cbpL, cbpC));
-                bad |= n < 0;
-                if (n >= 0) tcur[0] = (uint8_t)n;
-                DEC_WSYNC();
-            }
-            for (int i8 = 0; i8 < 4 && !bad; i8++)
-                if (cbpL & (1 << i8))
-                    for (int i4x = 0; i4x < 4 && !bad; i4x++) {
-                        int blk = i8 * 4 + i4x;
-                        int n = dec_block(b, &lut, lv + blk * 16, i16 ? 15 : 16, dec_nC(row, mbx, mby, true, blk, 0, tcur, cbpL, cbpC));
-                        bad |= n < 0;
-                        if (n >= 0) tcur[blk] = (uint8_t)n;
-                        DEC_WSYNC();
+                    bool edgeA = blk == 0 || blk == 2 || blk == 8 || blk == 10;
+                    bool edgeB = blk == 0 || blk == 1 || blk == 4 || blk == 5;
+                    bool okA = !(edgeA && mbx == 0), okB = !(edgeB && mby == 0);
+                    int mA = 2, mB = 2;
+                    if (okA && okB && !constrained_intra) {
+                        // c_nbA / c_nbB (the neighbouring block to the left / above), 4 bits per block: no table load in the chain
+                        const int nA = (int)((0xebc9af8d63412705ull >> (4 * blk)) & 15), nB = (int)((0xdc76983254fe10baull >> (4 * blk)) & 15);
+                        if (edgeA)
+                            mA = left_i4 ? (int)((left_modes >> (4 * nA)) & 15) : 2;
+                        else
+                            mA = (int)((cm >> (4 * nA)) & 15);
+                        if (edgeB)
+                            mB = above_i4 ? (int)((above_modes >> (4 * ((nB & 1) | ((nB >> 1) & 2)))) & 15) : 2;  // 10, 11, 14, 15 -> 0 .. 3
+                        else
+                            mB = (int)((cm >> (4 * nB)) & 15);
                     }
-            for (int pl = 0; pl < 2 && !bad; pl++)
-                if (cbpC & 3) bad |= dec_block(b, &lut, lv + FER_LV_CDC + pl * 4, 4, -1) < 0;
-            for (int pl = 0; pl < 2 && !bad; pl++)
-                for (int cb = 0; cb < 4 && !bad; cb++) {
-                    if (cbpC & 2) {
-                        for (int i = lane; i < 16; i += 64) cac[pl][cb][i] = 0;
-                        DEC_WSYNC();
-                        int n = dec_block(b, &lut, &cac[pl][cb][0], 15, dec_nC(row, mbx, mby, false, cb, pl, tcur, cbpL, cbpC));
-                        bad |= n < 0;
-                        if (n >= 0) tcur[16 + pl * 4 + cb] = (uint8_t)n;
-                        DEC_WSYNC();
-                    } else {
-                        for (int i = lane; i < 16; i += 64) cac[pl][cb][i] = 0;
-                        DEC_WSYNC();
-                    }
+                    int pm = mA <= mB ? mA : mB;
+                    int f = (int)((i4flags >> (4 * blk)) & 15);
+                    int mode = (f & 8) ? pm : ((f & 7) < pm ? (f & 7) : (f & 7) + 1);
+                    cm |= (unsigned long long)mode << (4 * blk);
                 }
-        }
-        DP_MARK(1)
-        if (bad) {
-            atomicOr(&d.status[s], FER_ERR_DEC_SYNTAX);
-            break;
-        }
-        // chroma AC of this macroblock = the persistent ChromaACLevel (stale when cbp == 0)
-        if (cbpL > 0 || cbpC > 0 || i16) cac_known = true;  // every block was parsed or cleared above
-        if (lane == 0) carry[cur] = cac_known ? 0 : 1;
-        for (int i = lane; i < 120; i += 64) lv[FER_LV_CAC + i] = cac[i / 60][(i % 60) / 15][i % 15];
-        DEC_WSYNC();
-        {  // the finished macroblock: levels to memory (one coalesced pass), counts into the neighbour row
-            uint32_t *g = (uint32_t *)(p_levels + mbi * FER_LEVELS);
-            for (int i = lane; i < FER_LEVELS / 2; i += 64) g[i] = ((const uint32_t *)mblv)[i];
-            DecNb &me = row[mbx];
-            if (lane < 24) {
-                p_tc[mbi * 24 + lane] = tcur[lane];
-                me.tc[lane] = tcur[lane];
+                if (lane < 16) p_i4mode[mbi * 16 + lane] = (uint8_t)((cm >> (4 * lane)) & 15);
+                if (lane == 0) i4row[mbx] = (uint16_t)(((cm >> 40) & 0xff) | (((cm >> 56) & 0xff) << 8));  // blocks 10, 11 | 14, 15
+                left_modes = cm;
             }
-            if (lane == 0) {
-                me.cbpL = (uint8_t)cbpL;
-                me.cbpC = (uint8_t)cbpC;
-                me.skip = 0;
-                me.i4 = i4 ? 1 : 0;
-            }
+            more = db_more(b);
+            cur++;
+            DP_MARK(2)
         }
-        DEC_WSYNC();
-        QPy = (QPy + mb_qp_delta + 52) % 52;
-        n_inherit += delta_known ? 0 : 1;
-        p_dec_qp[mbi] = (uint8_t)QPy;
-        if (inter) {
-            dec_derive_mvs(d, mvs, mbt, cur, t, mvd, sub);
-        } else if (i4) {
-            // getIntra4x4PredMode, F/intra.cpp:77-136
-            unsigned long long cm = 0;  // this macroblock's modes, 4 bits per block
-            for (int blk = 0; blk < 16; blk++) {
-                bool edgeA = blk == 0 || blk == 2 || blk == 8 || blk == 10;
-                bool edgeB = blk == 0 || blk == 1 || blk == 4 || blk == 5;
-                bool okA = !(edgeA && mbx == 0), okB = !(edgeB && mby == 0);
-                int mA = 2, mB = 2;
-                if (okA && okB && !constrained_intra) {
-                    // c_nbA / c_nbB (the neighbouring block to the left / above), 4 bits per block: no table load in the chain
-                    const int nA = (int)((0xebc9af8d63412705ull >> (4 * blk)) & 15), nB = (int)((0xdc76983254fe10baull >> (4 * blk)) & 15);
-                    if (edgeA)
-                        mA = left_i4 ? (int)((left_modes >> (4 * nA)) & 15) : 2;
-                    else
-                        mA = (int)((cm >> (4 * nA)) & 15);
-                    if (edgeB)
-                        mB = above_i4 ? (int)((above_modes >> (4 * ((nB & 1) | ((nB >> 1) & 2)))) & 15) : 2;  // 10, 11, 14, 15 -> 0 .. 3
-                    else
-                        mB = (int)((cm >> (4 * nB)) & 15);
-                }
-                int pm = mA <= mB ? mA : mB;
-                int f = (int)((i4flags >> (4 * blk)) & 15);
-                int mode = (f & 8) ? pm : ((f & 7) < pm ? (f & 7) : (f & 7) + 1);
-                cm |= (unsigned long long)mode << (4 * blk);
-            }
-            if (lane < 16) p_i4mode[mbi * 16 + lane] = (uint8_t)((cm >> (4 * lane)) & 15);
-            if (lane == 0) i4row[mbx] = (uint16_t)(((cm >> 40) & 0xff) | (((cm >> 56) & 0xff) << 8));  // blocks 10, 11 | 14, 15
-            left_modes = cm;
-        }
-        more = db_more(b);
-        cur++;
-        DP_MARK(2)
-    }
 #ifdef FER_PROBE
-    if (s == 0 && lane == 0) {
-        for (int k = 0; k < 4; k++) d.timing[48 + k] += tacc[k];
-        d.timing[52] += cur;
-    }
+        if (s == 0 && lane == 0) {
+            for (int k = 0; k < 4; k++) d.timing[48 + k] += tacc[k];
+            d.timing[52] += cur;
+        }
 #endif
 #undef DP_MARK
-    DEC_WSYNC();
-    for (int i = lane; i < 128; i += 64) B.cac_out[pic * 128 + i] = (&cac[0][0][0])[i];
-    if (lane == 0) {
-        st[1] = cur;  // macroblocks reached (the rest of the picture keeps the previous content)
-        summ[0] = delta_known;
-        summ[1] = mb_qp_delta;
-        summ[2] = n_inherit;
-        summ[3] = cac_known;
-    }
-    DEC_WSYNC();
+        DEC_WSYNC();
+        for (int i = lane; i < 128; i += 64) B.cac_out[pic * 128 + i] = (&cac[0][0][0])[i];
+        if (lane == 0) {
+            st[1] = cur;  // macroblocks reached (the rest of the picture keeps the previous content)
+            summ[0] = delta_known;
+            summ[1] = mb_qp_delta;
+            summ[2] = n_inherit;
+            summ[3] = cac_known;
+        }
+        DEC_WSYNC();
     }  // next picture
 }
 

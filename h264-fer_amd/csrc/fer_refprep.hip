@@ -900,25 +900,25 @@ __global__ __launch_bounds__(256) void k_sort_quirk(FerDev d, const uint32_t *re
     const int n = d.W * d.H;
     const size_t g0 = (size_t)s * n;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {  // place of the final array
-    const int ir = p + n0;   // the regular position that lands here (sorted index), if any
-    const int iz = p - n0;   // the sum-0 position aimed here, if any
-    const bool hr = ir < n, hz = iz >= 0 && iz < n0;
-    int src = -1;
-    if (hr && hz) {
-        const uint32_t vr = d.sort_pos[g0 + ir], vz = d.sort_pos[g0 + iz];
-        const int br = (int)(vr >> 16) * d.H + (int)(vr & 0xffff), bz = (int)(vz >> 16) * d.H + (int)(vz & 0xffff);
-        src = bz > br ? iz : ir;
-    } else if (hr) {
-        src = ir;
-    } else if (hz) {
-        src = iz;
-    }
-    if (src < 0) continue;  // keeps the previous picture's entry
-    const uint32_t *in = rec_tmp + (g0 + src) * 3;
-    uint32_t *o = d.sort_rec + (g0 + p) * 3;
-    o[0] = in[0];
-    o[1] = in[1];
-    o[2] = in[2];
+        const int ir = p + n0;   // the regular position that lands here (sorted index), if any
+        const int iz = p - n0;   // the sum-0 position aimed here, if any
+        const bool hr = ir < n, hz = iz >= 0 && iz < n0;
+        int src = -1;
+        if (hr && hz) {
+            const uint32_t vr = d.sort_pos[g0 + ir], vz = d.sort_pos[g0 + iz];
+            const int br = (int)(vr >> 16) * d.H + (int)(vr & 0xffff), bz = (int)(vz >> 16) * d.H + (int)(vz & 0xffff);
+            src = bz > br ? iz : ir;
+        } else if (hr) {
+            src = ir;
+        } else if (hz) {
+            src = iz;
+        }
+        if (src < 0) continue;  // keeps the previous picture's entry
+        const uint32_t *in = rec_tmp + (g0 + src) * 3;
+        uint32_t *o = d.sort_rec + (g0 + p) * 3;
+        o[0] = in[0];
+        o[1] = in[1];
+        o[2] = in[2];
     }
 }
 
